@@ -1,0 +1,179 @@
+"""Build libcomorag_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m comorag_amd.build [--force]
+
+Steps
+ 1. hipcc -c scan_kernels.hip with -save-temps → object + gfx950 assembly
+ 2. ISA audit of every inline-asm load-ring variant of the scan kernel (see `audit_ring`):
+    a variant whose ring registers are touched by compiler-generated code (after their first
+    asm load) is marked unsafe
+    and the library falls back to the compiler-counted ring for it → ring_audit.cpp
+ 3. hipcc -c aux_kernels.hip api.hip ring_audit.cpp ; link → comorag_amd/lib/libcomorag_hip.so
+The .so is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcomorag_hip.so")
+STAMP = os.path.join(LIBDIR, "build_stamp.json")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip"]
+HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
+
+_KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
+
+
+def _regs(text: str) -> set:
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]", text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bv(\d+)\b", text):
+        out.add(int(m.group(1)))
+    return out
+
+
+def audit_ring(asm_text: str) -> dict:
+    """For every scan_kernel<..., ASMRING=1> in the gfx950 assembly decide whether the hand-counted
+    load ring is safe: the ring's VGPRs (destinations of the global_load_dwordx4 inside
+    ;;#ASMSTART/;;#ASMEND) may be written only by that asm and read only by v_mfma; any other
+    compiler instruction touching them after the first ring load (a copy, a spill, a reuse)
+    could observe a slot before its data landed (cdna guide §5.7 item 1).  Also requires zero
+    scratch.  Returns {(dt,nqt,cap,ring,mode): bool}."""
+    result = {}
+    lines = asm_text.split("\n")
+    i = 0
+    while i < len(lines):
+        m = _KERNEL_RE.match(lines[i])
+        if not m:
+            i += 1
+            continue
+        dt, nqt, cap, ring, mode, asmring = (int(x) for x in m.groups())
+        j = i + 1
+        body = []
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            body.append(lines[j])
+            j += 1
+        i = j
+        if not asmring:
+            continue
+        in_asm = False
+        ring_regs: set = set()
+        for l in body:
+            s = l.strip()
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif s.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and s.startswith("global_load_dwordx4"):
+                ring_regs |= _regs(s.split(",")[0])
+        ok = len(ring_regs) == 4 * ring
+        loaded: set = set()   # ring registers that already received an asm load
+        in_asm = False
+        for l in body:
+            s = l.strip()
+            if not s or (s.startswith(";") and not s.startswith(";;#ASM")):
+                continue
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if s.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if in_asm:
+                if s.startswith("global_load_dwordx4"):
+                    loaded |= _regs(s.split(",")[0])
+                continue
+            if "scratch_" in s:
+                ok = False
+            code = s.split(";")[0]
+            if _regs(code) & loaded:
+                if code.startswith("v_mfma"):
+                    if _regs(code.split(",")[0]) & ring_regs:
+                        ok = False
+                else:
+                    ok = False
+        result[(dt, nqt, cap, ring, mode)] = ok
+    return result
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"command failed ({r.returncode}): {' '.join(cmd)}\n{r.stdout[-4000:]}")
+    return r.stdout
+
+
+def _source_hash() -> str:
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + [os.path.join("..", "build.py")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    want = _source_hash()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+        try:
+            if json.load(open(STAMP)).get("hash") == want:
+                return LIB
+        except Exception:
+            pass
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"{HIPCC} not found; cannot build libcomorag_hip.so")
+    with tempfile.TemporaryDirectory(prefix="cmr_build_") as tmp:
+        objs = []
+        # 1. scan kernels with assembly kept
+        _run([HIPCC, *FLAGS, "-save-temps", "-c", os.path.join(CSRC, "scan_kernels.hip"), "-o", "scan_kernels.o"], cwd=tmp)
+        objs.append(os.path.join(tmp, "scan_kernels.o"))
+        asm_file = os.path.join(tmp, f"scan_kernels-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+        audit = audit_ring(open(asm_file).read())
+        # 2. audit table
+        rows = ",\n".join(f"    {{{dt}, {nqt}, {cap}, {ring}, {mode}, {1 if ok else 0}}}"
+                          for (dt, nqt, cap, ring, mode), ok in sorted(audit.items()))
+        with open(os.path.join(tmp, "ring_audit.cpp"), "w") as f:
+            f.write("// generated by comorag_amd/build.py from the gfx950 assembly of scan_kernels.hip\n"
+                    "struct Row { int dt, nqt, cap, ring, mode, ok; };\n"
+                    f"static const Row kRows[] = {{\n{rows}\n}};\n"
+                    "bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring) {\n"
+                    "    bool any = false;\n"
+                    "    for (const Row& r : kRows)\n"
+                    "        if (r.dt == dtype && r.nqt == nqt && r.ring == ring && (r.mode == 1 || r.cap == cap)) {\n"
+                    "            if (!r.ok) return false;\n"
+                    "            any = true;\n"
+                    "        }\n"
+                    "    return any;\n"
+                    "}\n")
+        for src in ("aux_kernels.hip", "api.hip"):
+            o = os.path.join(tmp, src.replace(".hip", ".o"))
+            _run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", o], cwd=tmp)
+            objs.append(o)
+        o = os.path.join(tmp, "ring_audit.o")
+        _run([HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(tmp, "ring_audit.cpp"), "-o", o], cwd=tmp)
+        objs.append(o)
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+    n_ok = sum(audit.values())
+    info = {"hash": want, "arch": ARCH, "asm_ring_variants": len(audit), "asm_ring_safe": n_ok,
+            "unsafe": [list(k) for k, v in sorted(audit.items()) if not v]}
+    json.dump(info, open(STAMP, "w"), indent=1)
+    if verbose:
+        print(f"[comorag_amd.build] built {LIB}; asm-ring variants safe {n_ok}/{len(audit)}; unsafe: {info['unsafe']}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

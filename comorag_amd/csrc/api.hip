@@ -1,0 +1,684 @@
+// C-ABI of libcomorag_hip.so (include/comorag_hip.h): index lifetime, append, search, scores,
+// re-score, shard merge, encoder tail, profiling.  Host-side C++; every numeric step is a HIP
+// kernel from scan_kernels.hip / aux_kernels.hip.  There is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/comorag_hip.h"
+#include "cmr_kernels.h"
+
+#define CMR_DT_F32 0
+#define CMR_PANEL_ROWS 32
+#define CMR_SCAN_WAVES 8
+#define CMR_CORPUS_SLACK (32 * 1024)
+
+bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring);  // ring_audit.cpp (generated at build)
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            const int code_ = (e_ == hipErrorOutOfMemory) ? CMR_ERR_OOM                           \
+                              : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CMR_ERR_NO_DEVICE \
+                                                                                        : CMR_ERR_HIP; \
+            return fail(code_, "%s failed: %s", #expr, hipGetErrorString(e_));                    \
+        }                                                                                         \
+    } while (0)
+
+int elem_size(int dtype) { return dtype == CMR_F32 ? 4 : 2; }
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = std::max(need, cap * 2);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return e;
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// Scratch of one in-flight search.  One per stream (searches on a stream are serialised by it).
+struct Workspace {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevBuf qfrag, lists, cnt, mm, part, flag;
+    // host-API staging
+    DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
+    void release() {
+        qfrag.release(); lists.release(); cnt.release(); mm.release(); part.release(); flag.release();
+        d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct ProfEvent { hipEvent_t a, b; };
+
+}  // namespace
+
+struct cmr_index {
+    int device = 0;
+    int dim = 0, dpad = 0, dtype = 0;
+    uint32_t flags = 0;
+    int n_cu = 256;
+    long long n = 0;             // rows
+    long long cap_panels = 0;    // allocated panels
+    void* corpus = nullptr;      // panel-major blocks (+ slack)
+    float* shadow = nullptr;     // optional fp32 row-major [cap_rows, dim]
+    std::shared_mutex mu;        // searches shared, append/destroy exclusive
+    std::mutex ws_mu;
+    std::vector<Workspace*> free_ws;            // for the synchronous host API
+    std::map<hipStream_t, Workspace*> stream_ws;  // for the _dev API
+    DevBuf stage;                // append staging
+    int* d_flag = nullptr;       // non-finite flag for appends
+    // profiling
+    std::mutex prof_mu;
+    bool prof_on = false;
+    std::vector<ProfEvent> prof_events;
+    double prof_bytes = 0.0;
+    // knobs (env)
+    int force_ring = 0;      // CMR_SCAN_RING=8|16
+    int force_asm = -1;      // CMR_SCAN_ASM_RING=0|1
+    int force_grid = 0;      // CMR_SCAN_GRID
+    size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
+};
+
+namespace {
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+int set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return CMR_OK;
+}
+
+int check_device(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(CMR_ERR_NO_DEVICE, "no HIP device visible (%s); libcomorag_hip has no CPU fallback",
+                                               e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(CMR_ERR_NO_DEVICE, "device_id %d out of range [0,%d)", device_id, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CMR_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    return CMR_OK;
+}
+
+Workspace* acquire_ws(cmr_index* idx, hipStream_t user_stream, bool dev_api) {
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    if (dev_api && user_stream) {
+        auto it = idx->stream_ws.find(user_stream);
+        if (it != idx->stream_ws.end()) return it->second;
+        Workspace* w = new Workspace();
+        w->stream = user_stream;
+        idx->stream_ws[user_stream] = w;
+        return w;
+    }
+    if (dev_api) {  // NULL stream on the dev API: one dedicated own-stream workspace
+        auto it = idx->stream_ws.find(nullptr);
+        if (it != idx->stream_ws.end()) return it->second;
+        Workspace* w = new Workspace();
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+        w->own_stream = true;
+        idx->stream_ws[nullptr] = w;
+        return w;
+    }
+    if (!idx->free_ws.empty()) { Workspace* w = idx->free_ws.back(); idx->free_ws.pop_back(); return w; }
+    Workspace* w = new Workspace();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
+    w->own_stream = true;
+    return w;
+}
+void release_ws(cmr_index* idx, Workspace* w) {
+    std::lock_guard<std::mutex> g(idx->ws_mu);
+    idx->free_ws.push_back(w);
+}
+
+// Scan geometry for a pass of `nq` queries with top-`k`.
+int make_geom(cmr_index* idx, int nq, int k, bool topk, CmrScanGeom* g) {
+    const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
+    if (max_nqt == 0) return fail(CMR_ERR_UNSUPPORTED, "dim %d too large for the LDS-resident query tile (dtype %d)", idx->dim, idx->dtype);
+    g->dtype = idx->dtype;
+    g->dpad = idx->dpad;
+    g->nqt = (nq > 32 && max_nqt >= 2) ? 2 : 1;
+    g->cap = (topk && k > 32) ? 256 : 128;
+    const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
+    g->ring = (ks % 16 == 0) ? 16 : 8;
+    if (idx->force_ring == 8 || (idx->force_ring == 16 && ks % 16 == 0)) g->ring = idx->force_ring;
+    g->asm_ring = cmr_ring_audit_ok(g->dtype, g->nqt, g->cap, g->ring) ? 1 : 0;
+    if (idx->force_asm == 0) g->asm_ring = 0;
+    if (idx->force_asm == 1 && !cmr_ring_audit_ok(g->dtype, g->nqt, g->cap, g->ring))
+        return fail(CMR_ERR_UNSUPPORTED, "CMR_SCAN_ASM_RING=1 but variant (dtype %d nqt %d cap %d ring %d) failed the ISA audit", g->dtype, g->nqt, g->cap, g->ring);
+    if (!cmr_scan_geom(g)) return fail(CMR_ERR_UNSUPPORTED, "scan geometry does not fit LDS (dpad %d nqt %d)", idx->dpad, g->nqt);
+    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    const int bpc = g->lds <= 80 * 1024 ? 2 : 1;
+    long long grid = (npanels + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES;  // >= 1 panel per wave
+    grid = std::min<long long>(grid, (long long)idx->n_cu * bpc);
+    if (idx->force_grid > 0) grid = std::min<long long>(grid, idx->force_grid);
+    g->grid = (int)std::max<long long>(grid, 1);
+    return CMR_OK;
+}
+
+double algorithmic_bytes(const cmr_index* idx, int nq, int k) {
+    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    return (double)npanels * CMR_PANEL_ROWS * idx->dpad * elem_size(idx->dtype) + (double)nq * idx->dim * 4 + (double)nq * k * 12;
+}
+
+// Enqueue a full search (all passes) on ws->stream.  Device pointers in, device pointers out.
+int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev,
+                   float* min_dev, float* max_dev) {
+    hipStream_t s = ws->stream;
+    CmrScanGeom g;
+    const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
+    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
+    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    HIP_TRY(ws->flag.ensure(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    for (int q0 = 0; q0 < nq; q0 += per_pass) {
+        const int nqp = std::min(per_pass, nq - q0);
+        int rc = make_geom(idx, nqp, k, true, &g);
+        if (rc) return rc;
+        const int NQ = g.nqt * 32;
+        const int W = g.grid * CMR_SCAN_WAVES;
+        const int lpg = 32;
+        const int G = (W + lpg - 1) / lpg;
+        HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
+        HIP_TRY(ws->lists.ensure((size_t)W * NQ * g.cap * 8));
+        HIP_TRY(ws->cnt.ensure((size_t)W * NQ * 4));
+        HIP_TRY(ws->mm.ensure((size_t)W * NQ * 8));
+        HIP_TRY(ws->part.ensure((size_t)nqp * G * k * 8));
+        HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev + (size_t)q0 * idx->dim, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p,
+                                        (int*)ws->flag.p, s));
+        CmrScanArgs a{};
+        a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
+        a.lists = (u64*)ws->lists.p; a.cnt = (int*)ws->cnt.p; a.mm = (float2*)ws->mm.p;
+        ProfEvent pe{};
+        bool prof = false;
+        {
+            std::lock_guard<std::mutex> pg(idx->prof_mu);
+            prof = idx->prof_on;
+        }
+        if (prof) {
+            HIP_TRY(hipEventCreate(&pe.a));
+            HIP_TRY(hipEventCreate(&pe.b));
+            HIP_TRY(hipEventRecord(pe.a, s));
+        }
+        HIP_TRY(cmr_launch_scan_topk(g, a, s));
+        if (prof) {
+            HIP_TRY(hipEventRecord(pe.b, s));
+            std::lock_guard<std::mutex> pg(idx->prof_mu);
+            idx->prof_events.push_back(pe);
+            idx->prof_bytes = algorithmic_bytes(idx, nqp, k);
+        }
+        HIP_TRY(cmr_launch_merge_lists((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, lpg, (u64*)ws->part.p, s));
+        HIP_TRY(cmr_launch_final_topk((const u64*)ws->part.p, G, nqp, k, (const float2*)ws->mm.p, W, NQ, 0,
+                                      ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k,
+                                      min_dev ? min_dev + q0 : nullptr, max_dev ? max_dev + q0 : nullptr, s));
+    }
+    return CMR_OK;
+}
+
+int scores_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, float* out_dev, long long ld) {
+    hipStream_t s = ws->stream;
+    CmrScanGeom g;
+    const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
+    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
+    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    HIP_TRY(ws->flag.ensure(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    for (int q0 = 0; q0 < nq; q0 += per_pass) {
+        const int nqp = std::min(per_pass, nq - q0);
+        int rc = make_geom(idx, nqp, 1, false, &g);
+        if (rc) return rc;
+        HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
+        HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev + (size_t)q0 * idx->dim, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p,
+                                        (int*)ws->flag.p, s));
+        CmrScanArgs a{};
+        a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = 1;
+        a.scores = out_dev + (size_t)q0 * ld; a.ld = ld; a.nq = nqp;
+        HIP_TRY(cmr_launch_scan_scores(g, a, s));
+    }
+    return CMR_OK;
+}
+
+int check_query_flag(Workspace* ws) {
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, ws->flag.p, sizeof(int), hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    if (h) return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+    return CMR_OK;
+}
+
+int grow(cmr_index* idx, long long need_panels) {
+    if (need_panels <= idx->cap_panels) return CMR_OK;
+    long long new_cap = std::max(need_panels, idx->cap_panels * 2);
+    new_cap = std::max<long long>(new_cap, 8);
+    const size_t pb = idx->panel_bytes();
+    // outstanding async searches may still read the old buffer
+    HIP_TRY(hipDeviceSynchronize());
+    void* nc = nullptr;
+    HIP_TRY(hipMalloc(&nc, (size_t)new_cap * pb + CMR_CORPUS_SLACK));
+    HIP_TRY(hipMemsetAsync(nc, 0, (size_t)new_cap * pb + CMR_CORPUS_SLACK, nullptr));
+    const long long used_panels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    if (idx->corpus && used_panels)
+        HIP_TRY(hipMemcpyAsync(nc, idx->corpus, (size_t)used_panels * pb, hipMemcpyDeviceToDevice, nullptr));
+    float* ns = nullptr;
+    if ((idx->flags & CMR_FLAG_KEEP_F32) && idx->dtype != CMR_F32) {
+        HIP_TRY(hipMalloc((void**)&ns, (size_t)new_cap * CMR_PANEL_ROWS * idx->dim * sizeof(float)));
+        if (idx->shadow && idx->n)
+            HIP_TRY(hipMemcpyAsync(ns, idx->shadow, (size_t)idx->n * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (idx->corpus) HIP_TRY(hipFree(idx->corpus));
+    if (idx->shadow) HIP_TRY(hipFree(idx->shadow));
+    idx->corpus = nc;
+    idx->shadow = ns;
+    idx->cap_panels = new_cap;
+    return CMR_OK;
+}
+
+// rows_dev: fp32 [n, dim] on the device; converts on `s`, checks finiteness, bumps n.
+int append_from_device(cmr_index* idx, const float* rows_dev, long long n, hipStream_t s) {
+    HIP_TRY(hipMemsetAsync(idx->d_flag, 0, sizeof(int), s));
+    HIP_TRY(cmr_launch_convert_rows(idx->dtype, rows_dev, n, idx->dim, idx->dpad, idx->n, idx->corpus, idx->shadow, idx->d_flag, s));
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, idx->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h) return fail(CMR_ERR_NONFINITE, "appended rows contain NaN/Inf (index unchanged)");
+    idx->n += n;
+    return CMR_OK;
+}
+
+}  // namespace
+
+// ============================================================================================
+extern "C" {
+
+int32_t cmr_abi_version(void) { return CMR_ABI_VERSION; }
+const char* cmr_last_error(void) { return g_err.c_str(); }
+
+int32_t cmr_device_count(int32_t* n) {
+    if (!n) return fail(CMR_ERR_INVALID, "n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *n = (e == hipSuccess) ? c : 0;
+    return CMR_OK;
+}
+
+int32_t cmr_device_info(int32_t device_id, char* name, int32_t name_len, int32_t* n_cu, int64_t* hbm_bytes) {
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return CMR_OK;
+}
+
+int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t capacity_hint, uint32_t flags, cmr_index_t** out) {
+    if (!out) return fail(CMR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (dim <= 0 || dim > 16384) return fail(CMR_ERR_INVALID, "dim %d out of range", dim);
+    if (dtype != CMR_F32 && dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "unknown dtype %d", dtype);
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    cmr_index* idx = new cmr_index();
+    idx->device = device_id;
+    idx->dim = dim;
+    idx->dpad = round_up(dim, 128);
+    idx->dtype = dtype;
+    idx->flags = flags;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) idx->n_cu = prop.multiProcessorCount;
+    idx->force_ring = env_int("CMR_SCAN_RING", 0);
+    idx->force_asm = env_int("CMR_SCAN_ASM_RING", -1);
+    idx->force_grid = env_int("CMR_SCAN_GRID", 0);
+    if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
+        delete idx;
+        return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);
+    }
+    if (hipMalloc((void**)&idx->d_flag, sizeof(int)) != hipSuccess) { delete idx; return fail(CMR_ERR_OOM, "hipMalloc flag"); }
+    const long long hint_panels = std::max<long long>((capacity_hint + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS, 8);
+    rc = grow(idx, hint_panels);
+    if (rc) { (void)hipFree(idx->d_flag); delete idx; return rc; }
+    *out = idx;
+    return CMR_OK;
+}
+
+int32_t cmr_index_destroy(cmr_index_t* idx) {
+    if (!idx) return CMR_OK;
+    {
+        std::unique_lock<std::shared_mutex> lk(idx->mu);
+        (void)hipSetDevice(idx->device);
+        (void)hipDeviceSynchronize();
+        for (Workspace* w : idx->free_ws) { w->release(); delete w; }
+        for (auto& kv : idx->stream_ws) { kv.second->release(); delete kv.second; }
+        for (ProfEvent& pe : idx->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+        idx->stage.release();
+        if (idx->corpus) (void)hipFree(idx->corpus);
+        if (idx->shadow) (void)hipFree(idx->shadow);
+        if (idx->d_flag) (void)hipFree(idx->d_flag);
+    }
+    delete idx;
+    return CMR_OK;
+}
+
+int32_t cmr_index_size(cmr_index_t* idx, int64_t* n_rows) {
+    if (!idx || !n_rows) return fail(CMR_ERR_INVALID, "NULL argument");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    *n_rows = idx->n;
+    return CMR_OK;
+}
+
+int32_t cmr_index_info(cmr_index_t* idx, int32_t* dim, int32_t* dtype, int64_t* capacity_rows, int64_t* device_bytes) {
+    if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (dim) *dim = idx->dim;
+    if (dtype) *dtype = idx->dtype;
+    if (capacity_rows) *capacity_rows = idx->cap_panels * CMR_PANEL_ROWS;
+    if (device_bytes)
+        *device_bytes = (int64_t)(idx->cap_panels * idx->panel_bytes() + CMR_CORPUS_SLACK +
+                                  (idx->shadow ? (size_t)idx->cap_panels * CMR_PANEL_ROWS * idx->dim * 4 : 0));
+    return CMR_OK;
+}
+
+int32_t cmr_index_append(cmr_index_t* idx, const float* rows, int64_t n) {
+    if (!idx || (n > 0 && !rows)) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (n < 0) return fail(CMR_ERR_INVALID, "n < 0");
+    if (n == 0) return CMR_OK;
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (idx->n + n >= 0xFFFFFFF0ll) return fail(CMR_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    rc = grow(idx, (idx->n + n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
+    if (rc) return rc;
+    // stage in chunks of <= 256 MiB of fp32
+    const long long chunk_rows = std::max<long long>(1, (256ll << 20) / ((long long)idx->dim * 4));
+    const long long n0 = idx->n;
+    for (long long r0 = 0; r0 < n; r0 += chunk_rows) {
+        const long long nr = std::min<long long>(chunk_rows, n - r0);
+        const size_t bytes = (size_t)nr * idx->dim * 4;
+        hipError_t e = idx->stage.ensure(bytes);
+        if (e != hipSuccess) { idx->n = n0; return fail(CMR_ERR_OOM, "append staging: %s", hipGetErrorString(e)); }
+        e = hipMemcpyAsync(idx->stage.p, rows + (size_t)r0 * idx->dim, bytes, hipMemcpyHostToDevice, nullptr);
+        if (e != hipSuccess) { idx->n = n0; return fail(CMR_ERR_HIP, "H2D rows: %s", hipGetErrorString(e)); }
+        rc = append_from_device(idx, (const float*)idx->stage.p, nr, nullptr);
+        if (rc) { idx->n = n0; return rc; }
+    }
+    return CMR_OK;
+}
+
+int32_t cmr_index_append_dev(cmr_index_t* idx, const float* rows_dev, int64_t n, void* stream) {
+    if (!idx || (n > 0 && !rows_dev)) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (n <= 0) return n == 0 ? CMR_OK : fail(CMR_ERR_INVALID, "n < 0");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    if (idx->n + n >= 0xFFFFFFF0ll) return fail(CMR_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(s));  // rows_dev producer done before a possible grow() reallocates
+    rc = grow(idx, (idx->n + n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
+    if (rc) return rc;
+    return append_from_device(idx, rows_dev, n, s);
+}
+
+int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, int32_t k, int64_t* ids_dev, float* scores_dev,
+                             float* min_dev, float* max_dev, void* stream) {
+    if (!idx || !q_dev || !ids_dev || !scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K);
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, (hipStream_t)stream, true);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    return search_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
+}
+
+int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
+                         float* out_min, float* out_max) {
+    if (!idx || !q || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K);
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
+    hipStream_t s = ws->stream;
+    HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
+    HIP_TRY(ws->d_ids.ensure((size_t)nq * k * 8));
+    HIP_TRY(ws->d_scores.ensure((size_t)nq * k * 4));
+    HIP_TRY(ws->d_min.ensure((size_t)nq * 4));
+    HIP_TRY(ws->d_max.ensure((size_t)nq * 4));
+    HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
+    rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)ws->d_ids.p, (float*)ws->d_scores.p,
+                        (float*)ws->d_min.p, (float*)ws->d_max.p);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    HIP_TRY(hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+    if (out_min) HIP_TRY(hipMemcpyAsync(out_min, ws->d_min.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    if (out_max) HIP_TRY(hipMemcpyAsync(out_max, ws->d_max.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+    return check_query_flag(ws);
+}
+
+int32_t cmr_index_scores_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, float* out_dev, int64_t ld, void* stream) {
+    if (!idx || !q_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (ld == 0) ld = idx->n;
+    if (ld < idx->n) return fail(CMR_ERR_INVALID, "ld %lld < rows %lld", (long long)ld, idx->n);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, (hipStream_t)stream, true);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    if (idx->n == 0) return CMR_OK;
+    return scores_enqueue(idx, ws, q_dev, nq, out_dev, ld);
+}
+
+int32_t cmr_index_scores(cmr_index_t* idx, const float* q, int32_t nq, float* out, int64_t ld) {
+    if (!idx || !q || !out) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    if (ld == 0) ld = idx->n;
+    if (ld < idx->n) return fail(CMR_ERR_INVALID, "ld %lld < rows %lld", (long long)ld, idx->n);
+    if (idx->n == 0) return CMR_OK;
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
+    hipStream_t s = ws->stream;
+    HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
+    HIP_TRY(ws->d_out.ensure((size_t)nq * idx->n * 4));
+    HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
+    rc = scores_enqueue(idx, ws, (const float*)ws->d_q.p, nq, (float*)ws->d_out.p, idx->n);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld * 4, ws->d_out.p, (size_t)idx->n * 4, (size_t)idx->n * 4, (size_t)nq,
+                             hipMemcpyDeviceToHost, s));
+    return check_query_flag(ws);
+}
+
+int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const int64_t* cand, int32_t n_cand, int32_t k,
+                          int64_t* out_ids, float* out_scores) {
+    if (!idx || !q || !cand || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0 || n_cand <= 0 || k <= 0) return fail(CMR_ERR_INVALID, "nq, n_cand, k must be > 0");
+    if (n_cand > 4096) return fail(CMR_ERR_UNSUPPORTED, "n_cand %d > 4096", n_cand);
+    if (k > n_cand) k = n_cand;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
+    hipStream_t s = ws->stream;
+    HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
+    HIP_TRY(ws->d_cand.ensure((size_t)nq * n_cand * 8));
+    HIP_TRY(ws->d_ids.ensure((size_t)nq * k * 8));
+    HIP_TRY(ws->d_scores.ensure((size_t)nq * k * 4));
+    HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ws->d_cand.p, cand, (size_t)nq * n_cand * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, (const float*)ws->d_q.p, nq,
+                               (const int64_t*)ws->d_cand.p, n_cand, k, (int64_t*)ws->d_ids.p, (float*)ws->d_scores.p, s));
+    HIP_TRY(hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return CMR_OK;
+}
+
+int32_t cmr_index_get_rows(cmr_index_t* idx, const int64_t* ids, int64_t n, float* out) {
+    if (!idx || (n > 0 && (!ids || !out))) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (n <= 0) return CMR_OK;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
+    hipStream_t s = ws->stream;
+    HIP_TRY(ws->d_cand.ensure((size_t)n * 8));
+    HIP_TRY(ws->d_out.ensure((size_t)n * idx->dim * 4));
+    HIP_TRY(hipMemcpyAsync(ws->d_cand.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(cmr_launch_gather_rows(idx->dtype, idx->corpus, idx->dim, idx->dpad, idx->n, (const int64_t*)ws->d_cand.p, n,
+                                   (float*)ws->d_out.p, s));
+    HIP_TRY(hipMemcpyAsync(out, ws->d_out.p, (size_t)n * idx->dim * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return CMR_OK;
+}
+
+int32_t cmr_merge_topk(const int64_t* ids, const float* scores, int32_t S, int32_t nq, int32_t k, int64_t* out_ids,
+                       float* out_scores) {
+    // Host-side final merge (north_star: "host-side final merge" after the RCCL all-gather).
+    // Pure index/compare work on S*k <= a few hundred candidates per query; same tie rule.
+    if (!ids || !scores || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (S <= 0 || nq <= 0 || k <= 0) return fail(CMR_ERR_INVALID, "S, nq, k must be > 0");
+    std::vector<std::pair<float, int64_t>> v;
+    v.reserve((size_t)S * k);
+    for (int q = 0; q < nq; ++q) {
+        v.clear();
+        for (int s = 0; s < S; ++s)
+            for (int j = 0; j < k; ++j) {
+                const size_t o = ((size_t)s * nq + q) * k + j;
+                if (ids[o] >= 0) v.emplace_back(scores[o] + 0.0f, ids[o]);
+            }
+        std::sort(v.begin(), v.end(), [](const std::pair<float, int64_t>& a, const std::pair<float, int64_t>& b) {
+            return a.first > b.first || (a.first == b.first && a.second < b.second);
+        });
+        for (int j = 0; j < k; ++j) {
+            const bool have = (size_t)j < v.size();
+            out_ids[(size_t)q * k + j] = have ? v[j].second : -1;
+            out_scores[(size_t)q * k + j] = have ? v[j].first : -INFINITY;
+        }
+    }
+    return CMR_OK;
+}
+
+int32_t cmr_merge_topk_dev(int32_t device_id, const int64_t* ids_dev, const float* scores_dev, int32_t S, int32_t nq, int32_t k,
+                           int64_t* out_ids_dev, float* out_scores_dev, void* stream) {
+    if (!ids_dev || !scores_dev || !out_ids_dev || !out_scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (S <= 0 || nq <= 0 || k <= 0) return fail(CMR_ERR_INVALID, "S, nq, k must be > 0");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    HIP_TRY(cmr_launch_merge_shards(ids_dev, scores_dev, S, nq, k, out_ids_dev, out_scores_dev, (hipStream_t)stream));
+    return CMR_OK;
+}
+
+int32_t cmr_pool_l2norm(int32_t device_id, const void* hidden_dev, int32_t hidden_dtype, const int64_t* mask_dev, int32_t b,
+                        int32_t l, int32_t d, int32_t normalize, float* out_dev, void* stream) {
+    if (!hidden_dev || !mask_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (b <= 0 || l <= 0 || d <= 0) return fail(CMR_ERR_INVALID, "b, l, d must be > 0");
+    if (hidden_dtype != CMR_F32 && hidden_dtype != CMR_BF16 && hidden_dtype != CMR_F16) return fail(CMR_ERR_INVALID, "unknown dtype");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    const int splits = cmr_pool_splits(b, l, d);
+    // partials live in a per-device, per-stream scratch that grows on demand
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, DevBuf> scratch;
+    float* partial = nullptr;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        DevBuf& bf = scratch[{device_id, (hipStream_t)stream}];
+        if (bf.cap < (size_t)b * splits * d * 4) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        HIP_TRY(bf.ensure((size_t)b * splits * d * 4));
+        partial = (float*)bf.p;
+    }
+    HIP_TRY(cmr_launch_pool(hidden_dev, hidden_dtype, mask_dev, b, l, d, normalize, partial, out_dev, splits, (hipStream_t)stream));
+    return CMR_OK;
+}
+
+int32_t cmr_profile_enable(cmr_index_t* idx, int32_t on) {
+    if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
+    std::lock_guard<std::mutex> g(idx->prof_mu);
+    idx->prof_on = on != 0;
+    return CMR_OK;
+}
+
+int32_t cmr_profile_collect(cmr_index_t* idx, int64_t* n_launches, double* total_ms, double* bytes_per_launch) {
+    if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    std::vector<ProfEvent> ev;
+    double bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(idx->prof_mu);
+        ev.swap(idx->prof_events);
+        bytes = idx->prof_bytes;
+    }
+    double ms = 0;
+    for (ProfEvent& pe : ev) {
+        HIP_TRY(hipEventSynchronize(pe.b));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, pe.a, pe.b));
+        ms += t;
+        (void)hipEventDestroy(pe.a);
+        (void)hipEventDestroy(pe.b);
+    }
+    if (n_launches) *n_launches = (int64_t)ev.size();
+    if (total_ms) *total_ms = ms;
+    if (bytes_per_launch) *bytes_per_launch = bytes;
+    return CMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,456 @@
+// Small kernels around the corpus scan: operand packing (queries, appended rows), candidate
+// merges, exact re-score, row gather and the encoder tail (masked mean-pool + L2 normalise).
+// All are launch-latency or HBM bound; none uses MFMA.
+#include "cmr_device.h"
+#include "cmr_kernels.h"
+
+// ------------------------------------------------------------------------------------------
+// Pack element value by dtype.
+template <int DT> struct Pack;
+template <> struct Pack<CMR_DT_BF16> { static __device__ __forceinline__ unsigned short cvt(float f) { return cmr_f2bf(f); }
+                                       static __device__ __forceinline__ float back(unsigned short h) { return cmr_bf2f(h); } };
+template <> struct Pack<CMR_DT_F16>  { static __device__ __forceinline__ unsigned short cvt(float f) { return cmr_f2h(f); }
+                                       static __device__ __forceinline__ float back(unsigned short h) { return cmr_h2f(h); } };
+
+__device__ __forceinline__ bool cmr_finite(float f) { return (__float_as_uint(f) & 0x7F800000u) != 0x7F800000u; }
+
+// One thread builds one 16-byte lane slot of one block from a row-major fp32 source.
+//   src_row(row) -> pointer to the row's dim floats, or nullptr for a zero row
+template <int DT>
+__device__ __forceinline__ uint4 cmr_pack_slot(const float* row, int dim, int ks, int lane, bool& bad) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (row) {
+        if (DT == CMR_DT_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = cmr_blk_k<CMR_DT_F32>(ks, lane, e);
+                const float f = k < dim ? row[k] : 0.0f;
+                bad |= !cmr_finite(f);
+                w[e] = __float_as_uint(f);
+            }
+        } else {
+            const int k0 = cmr_blk_k<DT == CMR_DT_F32 ? CMR_DT_BF16 : DT>(ks, lane, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                const float f = k < dim ? row[k] : 0.0f;
+                bad |= !cmr_finite(f);
+                unsigned short h;
+                if (DT == CMR_DT_BF16) h = Pack<CMR_DT_BF16>::cvt(f); else h = Pack<CMR_DT_F16>::cvt(f);
+                w[e >> 1] |= (unsigned)h << (16 * (e & 1));
+            }
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// queries [nq, dim] fp32 -> qfrag [nqt][ks][64] uint4.   grid = nqt*ks blocks of 64 threads.
+template <int DT>
+__global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restrict__ q, int nq, int dim, int ks_total,
+                                                          uint4* __restrict__ qfrag, int* __restrict__ flag) {
+    const int blk = blockIdx.x;          // t*ks_total + ks
+    const int t = blk / ks_total, ks = blk % ks_total;
+    const int lane = threadIdx.x;
+    const int qi = t * 32 + (lane & 31);
+    bool bad = false;
+    const uint4 v = cmr_pack_slot<DT>(qi < nq ? q + (size_t)qi * dim : nullptr, dim, ks, lane, bad);
+    qfrag[(size_t)blk * 64 + lane] = v;
+    if (bad) atomicOr(flag, 1);
+}
+
+hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt, void* qfrag,
+                                   int* flag, hipStream_t s) {
+    const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
+    dim3 grid(nqt * ks), block(64);
+    uint4* o = reinterpret_cast<uint4*>(qfrag);
+    switch (dtype) {
+        case CMR_DT_BF16: hipLaunchKernelGGL(prep_queries_kernel<CMR_DT_BF16>, grid, block, 0, s, q, nq, dim, ks, o, flag); break;
+        case CMR_DT_F16:  hipLaunchKernelGGL(prep_queries_kernel<CMR_DT_F16>, grid, block, 0, s, q, nq, dim, ks, o, flag); break;
+        case CMR_DT_F32:  hipLaunchKernelGGL(prep_queries_kernel<CMR_DT_F32>, grid, block, 0, s, q, nq, dim, ks, o, flag); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// rows [n, dim] fp32 -> panel-major blocks starting at global row row0.
+// Work item = (panel-local row, half, ks) of one touched panel: a wave writes up to 64 adjacent
+// 16-byte slots of ONE block (coalesced), reading 32-byte pieces of 32 source rows.
+template <int DT>
+__global__ __launch_bounds__(256) void convert_rows_kernel(const float* __restrict__ rows, long long n, int dim, int ks_total,
+                                                           long long row0, uint4* __restrict__ corpus,
+                                                           float* __restrict__ shadow, int* __restrict__ flag) {
+    const long long first_panel = row0 / CMR_PANEL_ROWS;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;   // over touched_panels * ks * 64
+    const int lane = (int)(gid & 63);
+    const long long blk = gid >> 6;
+    const long long panel = first_panel + blk / ks_total;
+    const int ks = (int)(blk % ks_total);
+    const long long row = panel * CMR_PANEL_ROWS + (lane & 31);
+    if (row < row0 || row >= row0 + n) return;   // slot belongs to an older row or to padding
+    const float* src = rows + (size_t)(row - row0) * dim;
+    bool bad = false;
+    const uint4 v = cmr_pack_slot<DT>(src, dim, ks, lane, bad);
+    corpus[((size_t)panel * ks_total + ks) * 64 + lane] = v;
+    if (bad) atomicOr(flag, 1);
+    if (shadow && DT != CMR_DT_F32) {
+        // fp32 shadow, row-major [*, dim]: this thread owns the same 8 k of the row
+        const int k0 = cmr_blk_k<DT == CMR_DT_F32 ? CMR_DT_BF16 : DT>(ks, lane, 0);
+        for (int e = 0; e < 8; ++e)
+            if (k0 + e < dim) shadow[(size_t)row * dim + k0 + e] = src[k0 + e];
+    }
+}
+
+hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, int dim, int dpad, long long row0,
+                                   void* corpus, float* shadow, int* flag, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
+    const long long p_first = row0 / CMR_PANEL_ROWS, p_last = (row0 + n - 1) / CMR_PANEL_ROWS;
+    const long long items = (p_last - p_first + 1) * ks * 64;
+    dim3 grid((unsigned)((items + 255) / 256)), block(256);
+    uint4* o = reinterpret_cast<uint4*>(corpus);
+    switch (dtype) {
+        case CMR_DT_BF16: hipLaunchKernelGGL(convert_rows_kernel<CMR_DT_BF16>, grid, block, 0, s, rows, n, dim, ks, row0, o, shadow, flag); break;
+        case CMR_DT_F16:  hipLaunchKernelGGL(convert_rows_kernel<CMR_DT_F16>, grid, block, 0, s, rows, n, dim, ks, row0, o, shadow, flag); break;
+        case CMR_DT_F32:  hipLaunchKernelGGL(convert_rows_kernel<CMR_DT_F32>, grid, block, 0, s, rows, n, dim, ks, row0, o, shadow, flag); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage A of the candidate merge: (query q, group g of `lpg` wave lists) -> k best keys.
+__global__ __launch_bounds__(256) void merge_lists_kernel(const u64* __restrict__ lists, const int* __restrict__ cnt, int W,
+                                                          int nq_stride, int cap, int k, int lpg, u64* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    u64* pool = reinterpret_cast<u64*>(sm);                    // lpg*cap keys
+    u64* wbest = pool + (size_t)lpg * cap;                     // 4
+    int* offs = reinterpret_cast<int*>(wbest + 4);             // lpg+1
+    const int q = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = g * lpg;
+    const int nl = min(lpg, W - w0);
+    if (tid == 0) {
+        int o = 0;
+        for (int l = 0; l < nl; ++l) {
+            offs[l] = o;
+            int c = cnt[(size_t)(w0 + l) * nq_stride + q];
+            o += c < cap ? c : cap;
+        }
+        offs[nl] = o;
+    }
+    __syncthreads();
+    for (int l = wave; l < nl; l += 4) {
+        const int c = offs[l + 1] - offs[l];
+        const u64* L = lists + ((size_t)(w0 + l) * nq_stride + q) * cap;
+        for (int i = lane; i < c; i += 64) pool[offs[l] + i] = L[i];
+    }
+    __syncthreads();
+    cmr_block_select(pool, offs[nl], k, part + ((size_t)q * G + g) * k, wbest);
+}
+
+hipError_t cmr_launch_merge_lists(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
+                                  int lpg, u64* part, hipStream_t s) {
+    const int G = (W + lpg - 1) / lpg;
+    const size_t lds = (size_t)lpg * cap * 8 + 4 * 8 + (size_t)(lpg + 1) * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(merge_lists_kernel, dim3(nq, G), dim3(256), lds, s, lists, cnt, W, nq_stride, cap, k, lpg, part);
+    return hipGetLastError();
+}
+
+// Stage B: part[q][G][k] -> final ids/scores, plus min/max over the W waves' partials.
+__global__ __launch_bounds__(256) void final_topk_kernel(const u64* __restrict__ part, int G, int k, const float2* __restrict__ mm,
+                                                         int W, int nq_stride, long long id_base, int64_t* __restrict__ out_ids,
+                                                         float* __restrict__ out_scores, float* __restrict__ out_min,
+                                                         float* __restrict__ out_max) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    u64* pool = reinterpret_cast<u64*>(sm);          // G*k
+    u64* wbest = pool + (size_t)G * k;               // 4
+    u64* res = wbest + 4;                            // k
+    float* red = reinterpret_cast<float*>(res + k);  // 8
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = G * k;
+    for (int i = tid; i < n; i += 256) pool[i] = part[(size_t)q * n + i];
+    __syncthreads();
+    cmr_block_select(pool, n, k, res, wbest);
+    for (int i = tid; i < k; i += 256) {
+        const u64 key = res[i];
+        out_ids[(size_t)q * k + i] = key ? (int64_t)cmr_key_row(key) + id_base : -1;
+        out_scores[(size_t)q * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
+    }
+    if (out_min || out_max) {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int w = tid; w < W; w += 256) {
+            const float2 v = mm[(size_t)w * nq_stride + q];
+            mn = fminf(mn, v.x); mx = fmaxf(mx, v.y);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+            mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+            if (out_min) out_min[q] = mn;
+            if (out_max) out_max[q] = mx;
+        }
+    }
+}
+
+hipError_t cmr_launch_final_topk(const u64* part, int G, int nq, int k, const float2* mm, int W, int nq_stride,
+                                 long long id_base, int64_t* out_ids, float* out_scores, float* out_min,
+                                 float* out_max, hipStream_t s) {
+    const size_t lds = ((size_t)G * k + 4 + k) * 8 + 8 * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(final_topk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(final_topk_kernel, dim3(nq), dim3(256), lds, s, part, G, k, mm, W, nq_stride, id_base, out_ids,
+                       out_scores, out_min, out_max);
+    return hipGetLastError();
+}
+
+// Shard merge: ids/scores [S][nq][k] (global ids, -1 = empty) -> [nq][k], same order rule.
+// Keys are rebuilt on the fly; ids up to 2^63 are kept by ranking on (score, id) pairs directly.
+__global__ __launch_bounds__(64) void merge_shards_kernel(const int64_t* __restrict__ ids, const float* __restrict__ scores, int S,
+                                                          int nq, int k, int64_t* __restrict__ out_ids,
+                                                          float* __restrict__ out_scores) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int n = S * k;
+    // rank by counting (n = S*k is small: 8*20 = 160).  Entry i beats j if score higher, or equal and id lower.
+    for (int i = lane; i < k; i += 64) { out_ids[(size_t)q * k + i] = -1; out_scores[(size_t)q * k + i] = -__builtin_inff(); }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+        const int s = i / k, j = i % k;
+        const int64_t id = ids[((size_t)s * nq + q) * k + j];
+        if (id < 0) continue;
+        const float sc = scores[((size_t)s * nq + q) * k + j] + 0.0f;
+        int rank = 0;
+        for (int o = 0; o < n; ++o) {
+            const int so = o / k, jo = o % k;
+            const int64_t ido = ids[((size_t)so * nq + q) * k + jo];
+            if (ido < 0) continue;
+            const float sco = scores[((size_t)so * nq + q) * k + jo] + 0.0f;
+            rank += (sco > sc) || (sco == sc && ido < id);
+        }
+        if (rank < k) { out_ids[(size_t)q * k + rank] = id; out_scores[(size_t)q * k + rank] = sc; }
+    }
+}
+
+hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int S, int nq, int k, int64_t* out_ids,
+                                   float* out_scores, hipStream_t s) {
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(nq), dim3(64), 0, s, ids, scores, S, nq, k, out_ids, out_scores);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Row access in the panel-major layout.
+template <int DT>
+__device__ __forceinline__ float cmr_load_elem(const unsigned char* corpus, int ks_total, long long row, int kidx) {
+    const long long panel = row / CMR_PANEL_ROWS;
+    const int r = (int)(row % CMR_PANEL_ROWS);
+    if (DT == CMR_DT_F32) {
+        const int ks = kidx >> 3, w = kidx & 7, e = w >> 1, h = w & 1;
+        const size_t off = (((size_t)panel * ks_total + ks) * 64 + h * 32 + r) * 16 + e * 4;
+        return *reinterpret_cast<const float*>(corpus + off);
+    } else {
+        const int ks = kidx >> 4, w = kidx & 15, h = w >> 3, e = w & 7;
+        const size_t off = (((size_t)panel * ks_total + ks) * 64 + h * 32 + r) * 16 + e * 2;
+        const unsigned short v = *reinterpret_cast<const unsigned short*>(corpus + off);
+        return DT == CMR_DT_BF16 ? cmr_bf2f(v) : cmr_h2f(v);
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char* __restrict__ corpus, int dim, int ks_total,
+                                                          long long nrows, const int64_t* __restrict__ ids, long long n,
+                                                          float* __restrict__ out) {
+    const long long i = blockIdx.x;
+    const int64_t row = ids[i];
+    for (int kx = threadIdx.x; kx < dim; kx += 256)
+        out[(size_t)i * dim + kx] = (row >= 0 && row < nrows) ? cmr_load_elem<DT>(corpus, ks_total, row, kx) : 0.0f;
+}
+
+hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows, const int64_t* ids,
+                                  long long n, float* out, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
+    const unsigned char* c = reinterpret_cast<const unsigned char*>(corpus);
+    dim3 grid((unsigned)n), block(256);
+    switch (dtype) {
+        case CMR_DT_BF16: hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_BF16>, grid, block, 0, s, c, dim, ks, nrows, ids, n, out); break;
+        case CMR_DT_F16:  hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_F16>, grid, block, 0, s, c, dim, ks, nrows, ids, n, out); break;
+        case CMR_DT_F32:  hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_F32>, grid, block, 0, s, c, dim, ks, nrows, ids, n, out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Exact fp32 re-score: one workgroup per query; each wave takes candidates round-robin, the dot
+// is a fixed-order per-lane fmaf chain + butterfly (deterministic), then block top-k on keys
+// whose "row" field is the candidate row id.
+template <int DT>
+__global__ __launch_bounds__(256) void rescore_kernel(const unsigned char* __restrict__ corpus, const float* __restrict__ shadow,
+                                                      int dim, int ks_total, long long nrows, const float* __restrict__ q,
+                                                      const int64_t* __restrict__ cand, int n_cand, int k,
+                                                      int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    u64* pool = reinterpret_cast<u64*>(sm);      // n_cand
+    u64* wbest = pool + n_cand;                  // 4
+    u64* res = wbest + 4;                        // k
+    const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qv = q + (size_t)qi * dim;
+    for (int c = wave; c < n_cand; c += 4) {
+        const int64_t row = cand[(size_t)qi * n_cand + c];
+        u64 key = 0;
+        if (row >= 0 && row < nrows) {
+            float acc = 0.0f;
+            for (int kx = lane; kx < dim; kx += 64) {
+                const float x = shadow ? shadow[(size_t)row * dim + kx] : cmr_load_elem<DT>(corpus, ks_total, row, kx);
+                acc = fmaf(x, qv[kx], acc);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+            key = cmr_make_key(acc, (unsigned)row);
+        }
+        if (lane == 0) pool[c] = key;
+    }
+    __syncthreads();
+    // duplicates in cand would break uniqueness: keep the first occurrence only
+    for (int c = tid; c < n_cand; c += 256) {
+        const u64 key = pool[c];
+        if (!key) continue;
+        for (int o = 0; o < c; ++o) if (pool[o] == key) { pool[c] = 0; break; }
+    }
+    __syncthreads();
+    cmr_block_select(pool, n_cand, k, res, wbest);
+    for (int i = tid; i < k; i += 256) {
+        const u64 key = res[i];
+        out_ids[(size_t)qi * k + i] = key ? (int64_t)cmr_key_row(key) : -1;
+        out_scores[(size_t)qi * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
+    }
+}
+
+hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow, int dim, int dpad, long long nrows,
+                              const float* q, int nq, const int64_t* cand, int n_cand, int k, int64_t* out_ids,
+                              float* out_scores, hipStream_t s) {
+    const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
+    const unsigned char* c = reinterpret_cast<const unsigned char*>(corpus);
+    const size_t lds = ((size_t)n_cand + 4 + k) * 8;
+    dim3 grid(nq), block(256);
+#define RS(DT)                                                                                                        \
+    {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rescore_kernel<DT>),                         \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+        if (e != hipSuccess) return e;                                                                                \
+        hipLaunchKernelGGL(rescore_kernel<DT>, grid, block, lds, s, c, shadow, dim, ks, nrows, q, cand, n_cand, k,    \
+                           out_ids, out_scores);                                                                      \
+    }
+    switch (dtype) {
+        case CMR_DT_BF16: RS(CMR_DT_BF16) break;
+        case CMR_DT_F16: RS(CMR_DT_F16) break;
+        case CMR_DT_F32: RS(CMR_DT_F32) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef RS
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Encoder tail.  hidden [b, l, d] -> masked sum over l (split over `splits` workgroups per
+// batch row, fixed order inside each, partial[b][split][d]) -> finalize: sum partials in split
+// order, divide by the token count, L2-normalise (eps 1e-12, as F.normalize).
+template <typename T> __device__ __forceinline__ float cmr_to_f(T v);
+template <> __device__ __forceinline__ float cmr_to_f<float>(float v) { return v; }
+struct bf16_t { unsigned short v; };
+struct f16_t { unsigned short v; };
+template <> __device__ __forceinline__ float cmr_to_f<bf16_t>(bf16_t v) { return cmr_bf2f(v.v); }
+template <> __device__ __forceinline__ float cmr_to_f<f16_t>(f16_t v) { return cmr_h2f(v.v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_partial_kernel(const T* __restrict__ hidden, const int64_t* __restrict__ mask, int l,
+                                                           int d, int splits, float* __restrict__ partial) {
+    const int b = blockIdx.x, sp = blockIdx.y;
+    const int per = (l + splits - 1) / splits;
+    const int t0 = sp * per, t1 = min(l, t0 + per);
+    // each thread owns columns tid*VEC .. (+VEC) strided by 256*VEC: loads are contiguous per token row
+    constexpr int VEC = 16 / sizeof(T);
+    for (int c0 = threadIdx.x * VEC; c0 < d; c0 += 256 * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+        const bool full = c0 + VEC <= d && (d % VEC) == 0;
+        for (int t = t0; t < t1; ++t) {
+            if (mask[(size_t)b * l + t] == 0) continue;   // uniform across the block
+            const T* rowp = hidden + ((size_t)b * l + t) * d + c0;
+            if (full) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(rowp);
+                const T* e4 = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] += cmr_to_f<T>(e4[e]);
+            } else {
+                for (int e = 0; e < VEC; ++e) if (c0 + e < d) acc[e] += cmr_to_f<T>(rowp[e]);
+            }
+        }
+        for (int e = 0; e < VEC; ++e)
+            if (c0 + e < d) partial[((size_t)b * splits + sp) * d + c0 + e] = acc[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_finalize_kernel(const float* __restrict__ partial, const int64_t* __restrict__ mask,
+                                                            int l, int d, int splits, int normalize, float* __restrict__ out) {
+    __shared__ float red[4];
+    __shared__ float cnt_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // token count
+    float c = 0.0f;
+    for (int t = tid; t < l; t += 256) c += mask[(size_t)b * l + t] != 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if (lane == 0) red[wave] = c;
+    __syncthreads();
+    if (tid == 0) cnt_s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const float count = cnt_s;
+    float ss = 0.0f;
+    for (int cx = tid; cx < d; cx += 256) {
+        float s = 0.0f;
+        for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)b * splits + sp) * d + cx];
+        s = s / count;
+        out[(size_t)b * d + cx] = s;
+        ss += s * s;
+    }
+    if (!normalize) return;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    __syncthreads();
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float nrm = fmaxf(sqrtf(red[0] + red[1] + red[2] + red[3]), 1e-12f);
+    for (int cx = tid; cx < d; cx += 256) out[(size_t)b * d + cx] = out[(size_t)b * d + cx] / nrm;
+}
+
+int cmr_pool_splits(int b, int l, int d) {
+    // enough workgroups to cover the chip (>= ~1024) without making partials dominate traffic
+    int s = (1024 + b - 1) / b;
+    if (s > l / 8) s = l / 8;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    (void)d;
+    return s;
+}
+
+hipError_t cmr_launch_pool(const void* hidden, int hidden_dtype, const int64_t* mask, int b, int l, int d, int normalize,
+                           float* partial, float* out, int splits, hipStream_t s) {
+    dim3 grid(b, splits), block(256);
+    switch (hidden_dtype) {
+        case CMR_DT_F32: hipLaunchKernelGGL(pool_partial_kernel<float>, grid, block, 0, s, reinterpret_cast<const float*>(hidden), mask, l, d, splits, partial); break;
+        case CMR_DT_BF16: hipLaunchKernelGGL(pool_partial_kernel<bf16_t>, grid, block, 0, s, reinterpret_cast<const bf16_t*>(hidden), mask, l, d, splits, partial); break;
+        case CMR_DT_F16: hipLaunchKernelGGL(pool_partial_kernel<f16_t>, grid, block, 0, s, reinterpret_cast<const f16_t*>(hidden), mask, l, d, splits, partial); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3(b), dim3(256), 0, s, partial, mask, l, d, splits, normalize, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,72 @@
+// Host-callable launchers of the gfx950 kernels (defined in scan_kernels.hip / aux_kernels.hip).
+// All launchers enqueue on `stream` and return the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+struct CmrScanGeom {
+    int dtype;      // CMR_DT_*
+    int dpad;       // padded dim (multiple of 128)
+    int ks;         // 1-KiB blocks per panel  (dpad/16 for 16-bit, dpad/8 for fp32)
+    int nqt;        // query tiles of 32 per pass (1 or 2)
+    int cap;        // per-(wave,query) candidate list capacity (128 or 256)
+    int ring;       // register ring depth (8 or 16), ks % ring == 0
+    int grid;       // workgroups
+    int asm_ring;   // 1: hand-counted inline-asm load ring, 0: compiler-counted loads
+    size_t lds;     // dynamic LDS bytes
+};
+
+// max query tiles (1/2/0=unsupported) whose fragments fit LDS for this dtype/dpad
+int cmr_scan_max_nqt(int dtype, int dpad);
+// fills ks/lds for (dtype,dpad,nqt,cap); returns false if it does not fit
+bool cmr_scan_geom(CmrScanGeom* g);
+
+struct CmrScanArgs {
+    const void* corpus;   // panel-major blocks
+    const void* qfrag;    // [nqt][ks][64] uint4
+    long long nrows;
+    int npanels;
+    int k;
+    // top-k mode
+    u64* lists;           // [W][nqt*32][cap]
+    int* cnt;             // [W][nqt*32]
+    float2* mm;           // [W][nqt*32]  (min,max)
+    // scores mode
+    float* scores;        // [nq][ld]
+    long long ld;
+    int nq;
+};
+
+hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
+hipError_t cmr_launch_scan_scores(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
+
+// queries fp32 [nq, dim] (device) -> fragment-ordered blocks of the index dtype, zero padded
+hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt,
+                                   void* qfrag, int* nonfinite_flag, hipStream_t s);
+// rows fp32 [n, dim] (device) -> panel-major blocks at row offset row0 (+ optional fp32 shadow)
+hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, int dim, int dpad,
+                                   long long row0, void* corpus, float* shadow, int* nonfinite_flag,
+                                   hipStream_t s);
+// per-wave lists -> per-group top-k keys: part[q][G][k]
+hipError_t cmr_launch_merge_lists(const u64* lists, const int* cnt, int W, int nq_stride, int cap,
+                                  int nq, int k, int lists_per_group, u64* part, hipStream_t s);
+// part[q][G][k] -> ids/scores (+ min/max over W waves)
+hipError_t cmr_launch_final_topk(const u64* part, int G, int nq, int k, const float2* mm, int W,
+                                 int nq_stride, long long id_base, int64_t* out_ids, float* out_scores,
+                                 float* out_min, float* out_max, hipStream_t s);
+// shard merge: ids/scores [S][nq][k] -> [nq][k]
+hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int S, int nq, int k,
+                                   int64_t* out_ids, float* out_scores, hipStream_t s);
+// exact fp32 dot of queries with candidate rows, then top-k
+hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow, int dim, int dpad,
+                              long long nrows, const float* q, int nq, const int64_t* cand, int n_cand,
+                              int k, int64_t* out_ids, float* out_scores, hipStream_t s);
+// gather rows as fp32
+hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows,
+                                  const int64_t* ids, long long n, float* out, hipStream_t s);
+// masked mean-pool + L2 norm
+hipError_t cmr_launch_pool(const void* hidden, int hidden_dtype, const int64_t* mask, int b, int l, int d,
+                           int normalize, float* partial, float* out, int splits, hipStream_t s);
+int cmr_pool_splits(int b, int l, int d);

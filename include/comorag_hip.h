@@ -1,0 +1,153 @@
+/*
+ * comorag_hip.h — C-ABI of libcomorag_hip.so, the MI355X (gfx950) dense-retrieval engine
+ * behind ComoRAG's EmbeddingModel / EmbeddingStore Python API.
+ *
+ * The reference (EternityJune25/ComoRAG @ 2025-08-29) has no FFI: its boundary for this path is
+ * duck-typed Python.  Each entry point below names the reference code whose
+ * numeric work it replaces (paths relative to src/comorag/).  The Python host side
+ * (comorag_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - every function returns int32 status: 0 = CMR_OK, < 0 = error; cmr_last_error() returns a
+ *    thread-local NUL-terminated message valid until the next call on that thread.
+ *  - host buffers are caller-owned, C-contiguous, never retained after return.
+ *  - "_dev" variants take DEVICE pointers (e.g. torch tensors' data_ptr()) and a hipStream_t
+ *    passed as void* (NULL = the index's own stream); they enqueue work and return without
+ *    synchronising.  Calls on one stream must not be issued concurrently from several threads.
+ *  - handles are opaque; destroy(NULL) is a no-op.  All functions are thread-safe: searches on
+ *    one index run concurrently (shared lock), append/destroy are exclusive.
+ *  - there is NO CPU fallback: without a visible gfx950 device every compute call fails with
+ *    CMR_ERR_NO_DEVICE.
+ *
+ * Result order (exported tie rule): score descending, then row index ascending.  Scores on the
+ * wire are RAW inner products; ComoRAG's min-max normalisation (utils/misc_utils.py:141-150) is
+ * applied by the Python layer from out_min/out_max so its formula stays textually the
+ * reference's.  Inputs must be finite (checked: CMR_ERR_NONFINITE).
+ */
+#ifndef COMORAG_HIP_H
+#define COMORAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMR_ABI_VERSION 1
+
+enum cmr_status {
+    CMR_OK = 0,
+    CMR_ERR_INVALID = -1,     /* bad argument */
+    CMR_ERR_NO_DEVICE = -2,   /* no usable HIP device / wrong arch */
+    CMR_ERR_HIP = -3,         /* a HIP runtime call failed (message has the call) */
+    CMR_ERR_OOM = -4,
+    CMR_ERR_NONFINITE = -5,   /* NaN/Inf in rows or queries */
+    CMR_ERR_UNSUPPORTED = -6  /* e.g. k above CMR_MAX_K */
+};
+
+enum cmr_dtype { CMR_F32 = 0, CMR_BF16 = 1, CMR_F16 = 2 };
+
+/* index flags */
+#define CMR_FLAG_KEEP_F32 1u /* also keep a row-major fp32 shadow (exact re-score, C5) */
+
+#define CMR_MAX_K 128 /* largest k served by the fused scan+top-k kernel */
+
+typedef struct cmr_index cmr_index_t;
+
+/* ---- library --------------------------------------------------------------------------- */
+int32_t cmr_abi_version(void);
+const char* cmr_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only host; never an error there) */
+int32_t cmr_device_count(int32_t* n);
+/* name / arch / CU count / HBM bytes of a device — bench.py prints this next to the roofline */
+int32_t cmr_device_info(int32_t device_id, char* name, int32_t name_len, int32_t* n_cu,
+                        int64_t* hbm_bytes);
+
+/* ---- index lifecycle -------------------------------------------------------------------
+ * Replaces the dense matrices ComoRAG.prepare_retrieval_objects materialises on the host
+ * (ComoRAG.py:896-900: np.array(store.get_embeddings(keys)) x3-4) and
+ * EmbeddingStore.get_embeddings' per-call N x D copy (embedding_store.py:150-157).
+ * Storage: HBM-resident, MFMA-fragment-major panels of 32 rows; dim is padded
+ * to a multiple of 128 with zeros.  capacity grows x2 (device-to-device hipMemcpyAsync).      */
+int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t capacity_hint,
+                         uint32_t flags, cmr_index_t** out);
+int32_t cmr_index_destroy(cmr_index_t* idx);
+int32_t cmr_index_size(cmr_index_t* idx, int64_t* n_rows);
+int32_t cmr_index_info(cmr_index_t* idx, int32_t* dim, int32_t* dtype, int64_t* capacity_rows,
+                       int64_t* device_bytes);
+
+/* Append n rows (fp32, row-major [n, dim]); converted round-to-nearest-even to the index dtype
+ * on the device.  Row ids are assigned densely in append order (id = previous size + i) — the
+ * same order EmbeddingStore._upsert extends its lists (embedding_store.py:122-128), so
+ * hash_id_to_idx stays valid as the row id.  The memory-pool appends of the probe loop
+ * (utils/memory_utils.py:176,297-300) use this too (BASELINE config 4).                        */
+int32_t cmr_index_append(cmr_index_t* idx, const float* rows_f32, int64_t n);
+int32_t cmr_index_append_dev(cmr_index_t* idx, const float* rows_f32_dev, int64_t n, void* stream);
+
+/* ---- search ----------------------------------------------------------------------------
+ * Fused scan + per-query top-k + global min/max of the raw scores.
+ * Replaces np.dot + min_max_normalize + argsort in ComoRAG.dense_passage_retrieval
+ * (ComoRAG.py:950-967), get_fact_scores + link_top_k argsort (ComoRAG.py:937-948,1073),
+ * get_similar_summaries (utils/embed_utils.py:152-158), the python-loop cosine of
+ * MemoryPool.retrieve_similar_nodes (utils/memory_utils.py:213-227) and each
+ * torch.mm + torch.topk block of retrieve_knn (utils/embed_utils.py:52-78) for k <= CMR_MAX_K.
+ *   q        [nq, dim] fp32 (rounded to the index dtype for bf16/f16 indexes, as BASELINE.md §2)
+ *   out_ids  [nq, k] int64 row ids, -1 padded when the index has < k rows
+ *   out_scores [nq, k] fp32 raw inner products, descending, -inf padded
+ *   out_min/out_max [nq] fp32 over ALL rows (NULL allowed)                                     */
+int32_t cmr_index_search(cmr_index_t* idx, const float* q_f32, int32_t nq, int32_t k,
+                         int64_t* out_ids, float* out_scores, float* out_min, float* out_max);
+int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
+                             int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
+                             float* out_max_dev, void* stream);
+
+/* All N raw scores per query, out [nq, ld] fp32 (ld >= N; ld = N when 0).  For the callers that
+ * consume every score: graph_search_with_fact_entities reads all (id, score) pairs of
+ * dense_passage_retrieval (ComoRAG.py:1034-1042) and get_fact_scores returns the full vector
+ * (ComoRAG.py:937-948).                                                                        */
+int32_t cmr_index_scores(cmr_index_t* idx, const float* q_f32, int32_t nq, float* out, int64_t ld);
+int32_t cmr_index_scores_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, float* out_dev,
+                             int64_t ld, void* stream);
+
+/* Exact fp32 re-score of candidate rows (BASELINE config 5 "cross-scores on top-100").  The
+ * reference's rerank.py is an LLM filter with no numeric scoring (rerank.py:100-123); this is
+ * the numeric stage the engine adds behind the same (indices, items, {'confidence'}) shape.
+ * Uses the fp32 shadow when the index was created with CMR_FLAG_KEEP_F32, otherwise the stored
+ * (rounded) rows with fp32 queries.  cand [nq, n_cand] int64 row ids (-1 = skip).              */
+int32_t cmr_index_rescore(cmr_index_t* idx, const float* q_f32, int32_t nq, const int64_t* cand,
+                          int32_t n_cand, int32_t k, int64_t* out_ids, float* out_scores);
+
+/* Gather rows back to the host as fp32 (dequantised), out [n, dim]. */
+int32_t cmr_index_get_rows(cmr_index_t* idx, const int64_t* ids, int64_t n, float* out);
+
+/* ---- multi-shard merge ------------------------------------------------------------------
+ * Final merge of per-shard candidates after the RCCL all-gather (no reference counterpart;
+ * SURVEY.md §8e).  ids/scores [n_shards, nq, k] (ids already global, -1 = empty); same tie rule,
+ * so the result equals a single-shard search.  Host version and device version.               */
+int32_t cmr_merge_topk(const int64_t* ids, const float* scores, int32_t n_shards, int32_t nq,
+                       int32_t k, int64_t* out_ids, float* out_scores);
+int32_t cmr_merge_topk_dev(int32_t device_id, const int64_t* ids_dev, const float* scores_dev,
+                           int32_t n_shards, int32_t nq, int32_t k, int64_t* out_ids_dev,
+                           float* out_scores_dev, void* stream);
+
+/* ---- encoder tail -----------------------------------------------------------------------
+ * Fused masked mean-pool + L2-normalise of the encoder's last hidden state; replaces
+ * mean_pooling (embedding_model/BGEEmbedding.py:15-28) + F.normalize (:126-127, eps 1e-12).
+ *   hidden_dev [b, l, d] of hidden_dtype (cmr_dtype), mask_dev [b, l] int64 (HF attention_mask),
+ *   out_dev [b, d] fp32.  normalize = 0 gives the plain masked mean.                           */
+int32_t cmr_pool_l2norm(int32_t device_id, const void* hidden_dev, int32_t hidden_dtype,
+                        const int64_t* mask_dev, int32_t b, int32_t l, int32_t d, int32_t normalize,
+                        float* out_dev, void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------
+ * HIP-event timing of the dominant kernel (the corpus scan) on the stream it is launched on.
+ * enable → run searches → collect returns launches, summed kernel ms and the algorithmic bytes
+ * one launch reads (N_pad*Dpad*sizeof(elem) + query/result bytes), then resets.               */
+int32_t cmr_profile_enable(cmr_index_t* idx, int32_t on);
+int32_t cmr_profile_collect(cmr_index_t* idx, int64_t* n_launches, double* total_ms,
+                            double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMORAG_HIP_H */

@@ -1,0 +1,261 @@
+"""GPU parity of the HIP scan / top-k path against the oracle (oracle/retrieval_np.py) and the
+reference-generated golden fixtures.  Everything goes through the C-ABI (ctypes)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import retrieval_np as orc
+
+pytestmark = pytest.mark.gpu
+
+ROUND = {"bf16": orc.bf16_round, "f16": orc.f16_round, "f32": lambda x: np.asarray(x, np.float32)}
+# |fp32-accumulated dot - exact| for unit-norm rows: D * 2^-24 * sum|a_i b_i| <= ~D*6e-8*1 ; generous
+ERR = 4e-6
+
+
+def _mk(n, d, nq, seed=0):
+    X = orc.synthetic_corpus(n, d, seed=100 + seed)
+    Q = orc.synthetic_queries(nq, d, seed=200 + seed, planted=X)
+    return X, Q
+
+
+def _check(index_dtype, X, Q, k, env=None):
+    from comorag_amd.index import DenseIndex
+    old = {}
+    for kk, v in (env or {}).items():
+        old[kk] = os.environ.get(kk)
+        os.environ[kk] = v
+    try:
+        idx = DenseIndex(X.shape[1], index_dtype)
+        idx.append(X)
+        ids, sc, mn, mx = idx.search(Q, k)
+    finally:
+        for kk, v in old.items():
+            if v is None:
+                os.environ.pop(kk, None)
+            else:
+                os.environ[kk] = v
+    rnd = ROUND[index_dtype]
+    exact = orc.exact_scores_f64(rnd(X), rnd(Q))
+    ref_ids, ref_sc = orc.topk_rule(exact, k)
+    assert ids.shape == ref_ids.shape
+    for i in range(Q.shape[0]):
+        orc.assert_topk_equivalent(ids[i], ref_ids[i], exact[i], ERR)
+        np.testing.assert_allclose(sc[i], exact[i][ids[i]], atol=ERR, rtol=0)
+        assert np.all(np.diff(sc[i]) <= 0), "scores not descending"
+    np.testing.assert_allclose(mn, exact.min(axis=1), atol=ERR)
+    np.testing.assert_allclose(mx, exact.max(axis=1), atol=ERR)
+    idx.close()
+    return ids, sc
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 64, 65, 257, 1000])
+def test_small_shapes(dtype, n):
+    X, Q = _mk(n, 48, 5, seed=n)
+    _check(dtype, X, Q, 5)
+
+
+@pytest.mark.parametrize("dtype,d", [("bf16", 8), ("bf16", 128), ("bf16", 768), ("bf16", 1024), ("f16", 1024),
+                                     ("f32", 768), ("f32", 100), ("bf16", 200)])
+def test_dims(dtype, d):
+    X, Q = _mk(3001, d, 9, seed=d)
+    _check(dtype, X, Q, 20)
+
+
+@pytest.mark.parametrize("nq", [1, 31, 32, 33, 64, 65, 130])
+def test_batch_sizes(nq):
+    X, Q = _mk(5000, 256, nq, seed=nq)
+    _check("bf16", X, Q, 20)
+    if nq in (1, 33, 65):
+        _check("f32", X, Q, 20)
+
+
+@pytest.mark.parametrize("k", [1, 5, 20, 32, 33, 100, 128])
+def test_k_values(k):
+    X, Q = _mk(4000, 128, 7, seed=k)
+    _check("bf16", X, Q, k)
+
+
+@pytest.mark.parametrize("env", [{"CMR_SCAN_ASM_RING": "0"}, {"CMR_SCAN_ASM_RING": "0", "CMR_SCAN_RING": "8"},
+                                 {"CMR_SCAN_RING": "8"}, {"CMR_SCAN_RING": "16"}, {"CMR_SCAN_GRID": "3"}])
+def test_ring_variants_agree(env):
+    X, Q = _mk(70001, 768, 64, seed=7)
+    a_ids, a_sc = _check("bf16", X, Q, 20)
+    b_ids, b_sc = _check("bf16", X, Q, 20, env=env)
+    # same arithmetic in every variant (same MFMA order) -> bitwise equal
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+
+
+def test_ties_index_ascending():
+    from comorag_amd.index import DenseIndex
+    X = orc.synthetic_corpus(500, 64, seed=5)
+    X[100] = X[7]; X[300] = X[7]; X[499] = X[7]
+    q = X[7:8].copy()
+    for dtype in ("bf16", "f32"):
+        idx = DenseIndex(64, dtype); idx.append(X)
+        ids, sc, _, _ = idx.search(q, 6)
+        assert ids[0, :4].tolist() == [7, 100, 300, 499], ids
+        assert sc[0, 0] == sc[0, 1] == sc[0, 2] == sc[0, 3]
+        idx.close()
+    # all-equal scores: every row identical -> first k rows in index order
+    Z = np.tile(X[3:4], (200, 1))
+    idx = DenseIndex(64, "bf16"); idx.append(Z)
+    ids, sc, mn, mx = idx.search(q, 10)
+    assert ids[0].tolist() == list(range(10)) and mn[0] == mx[0]
+    idx.close()
+
+
+def test_k_larger_than_n_and_empty():
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(7, 32, 3)
+    idx = DenseIndex(32, "bf16"); idx.append(X)
+    ids, sc, mn, mx = idx.search(Q, 20)
+    assert ids.shape == (3, 7) and len(set(ids[0].tolist())) == 7
+    e = DenseIndex(32, "bf16")
+    ids, sc, mn, mx = e.search(Q, 5)
+    assert ids.shape == (3, 0)
+    idx.close(); e.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_incremental_append_equals_bulk(dtype):
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(3000, 96, 8, seed=3)
+    a = DenseIndex(96, dtype, capacity_hint=16); b = DenseIndex(96, dtype)
+    b.append(X)
+    for lo, hi in ((0, 1), (1, 2), (2, 33), (33, 64), (64, 65), (65, 1000), (1000, 1025), (1025, 3000)):
+        a.append(X[lo:hi])       # forces several capacity doublings (hipMemcpyAsync grow)
+    assert len(a) == len(b) == 3000
+    ia, sa, mna, mxa = a.search(Q, 20); ib, sb, mnb, mxb = b.search(Q, 20)
+    assert np.array_equal(ia, ib) and np.array_equal(sa, sb) and np.array_equal(mna, mnb) and np.array_equal(mxa, mxb)
+    rows = a.get_rows([0, 31, 32, 2999])
+    np.testing.assert_array_equal(rows, ROUND[dtype](X[[0, 31, 32, 2999]]))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+def test_full_scores(dtype):
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(2077, 192, 37, seed=11)
+    idx = DenseIndex(192, dtype); idx.append(X)
+    s = idx.scores(Q)
+    exact = orc.exact_scores_f64(ROUND[dtype](X), ROUND[dtype](Q))
+    np.testing.assert_allclose(s, exact, atol=ERR, rtol=0)
+    # top-k of the full-score output equals the fused top-k (same arithmetic order? no: operand
+    # roles are swapped but each score is the same k-ordered fp32 chain) -> ids must agree
+    ids, sc, _, _ = idx.search(Q, 10)
+    rid, _ = orc.topk_rule(s, 10)
+    for i in range(len(Q)):
+        orc.assert_topk_equivalent(ids[i], rid[i], exact[i], ERR)
+    idx.close()
+
+
+def test_nonfinite_rejected():
+    from comorag_amd.index import DenseIndex
+    from comorag_amd._lib import CmrError, CMR_ERR_NONFINITE
+    X, Q = _mk(100, 32, 2)
+    idx = DenseIndex(32, "bf16"); idx.append(X)
+    bad = X[:3].copy(); bad[1, 5] = np.nan
+    with pytest.raises(CmrError) as ei:
+        idx.append(bad)
+    assert ei.value.code == CMR_ERR_NONFINITE and len(idx) == 100
+    qb = Q.copy(); qb[0, 0] = np.inf
+    with pytest.raises(CmrError):
+        idx.search(qb, 3)
+    ids, _, _, _ = idx.search(Q, 3)   # still usable
+    assert ids.shape == (2, 3)
+    idx.close()
+
+
+def test_golden_dpr_fp32(golden_dir):
+    """fp32 index vs the REFERENCE's dense_passage_retrieval / get_fact_scores outputs."""
+    from comorag_amd.index import DenseIndex
+    for tag in ("small", "mid", "d768", "n2"):
+        g = np.load(os.path.join(golden_dir, f"dpr_{tag}.npz"))
+        X, F, Q = g["X"], g["F"], g["Q"]
+        idx = DenseIndex(X.shape[1], "f32"); idx.append(X)
+        fidx = DenseIndex(F.shape[1], "f32"); fidx.append(F)
+        exact = orc.exact_scores_f64(X, Q)
+        k = min(20, len(X))
+        ids, sc, mn, mx = idx.search(Q, k)
+        full = fidx.scores(Q)
+        for i in range(len(Q)):
+            ref_ids, ref_sc = g[f"dpr_ids_{i}"], g[f"dpr_scores_{i}"]
+            orc.assert_topk_equivalent(ids[i], ref_ids[:k], exact[i], 1e-6)
+            norm = (sc[i] - mn[i]) / (mx[i] - mn[i])        # misc_utils.py:141-150 from out_min/out_max
+            np.testing.assert_allclose(norm, ref_sc[:k], atol=2e-6)
+            fs = orc.min_max_normalize(full[i])
+            np.testing.assert_allclose(fs, g[f"fact_scores_{i}"], atol=2e-6)
+        idx.close(); fidx.close()
+
+
+def test_rescore_exact():
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(3000, 1024, 4, seed=21)
+    idx = DenseIndex(1024, "f16", keep_f32=True); idx.append(X)
+    ids, _, _, _ = idx.search(Q, 100)
+    rid, rsc = idx.rescore(Q, ids, 20)
+    exact = orc.exact_scores_f64(X, Q)           # fp32 shadow: un-rounded rows, fp32 queries
+    for i in range(len(Q)):
+        cand = ids[i]
+        order = cand[np.lexsort((cand, -exact[i][cand]))][:20]
+        orc.assert_topk_equivalent(rid[i], order, exact[i], 1e-6)
+        np.testing.assert_allclose(rsc[i], exact[i][rid[i]], atol=1e-6)
+    idx.close()
+
+
+def test_threads_concurrent_search():
+    """16 Python threads on one index (ComoRAG.try_answer's pool, ComoRAG.py:436-441)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(20000, 128, 32, seed=9)
+    idx = DenseIndex(128, "bf16"); idx.append(X)
+    want = idx.search(Q, 10)[0]
+    def work(i):
+        return idx.search(Q[i:i + 2], 10)[0]
+    with ThreadPoolExecutor(16) as ex:
+        outs = list(ex.map(work, list(range(0, 32, 2)) * 4))
+    for j, o in enumerate(outs):
+        i = (j % 16) * 2
+        assert np.array_equal(o, want[i:i + 2])
+    idx.close()
+
+
+def test_c2_size_properties():
+    """BASELINE config 2 size: 1M x 768 bf16, B=64, k=20 — oracle on the full size (numpy fp32 BLAS,
+    fp64 arbitration on disagreements) + planted rows + shard-merge equivalence."""
+    from comorag_amd.index import DenseIndex, merge_topk
+    n, d, b, k = 1_000_000, 768, 64, 20
+    X = np.concatenate([orc.synthetic_corpus(250_000, d, seed=1234, block=i) for i in range(4)])
+    Q = orc.synthetic_queries(b, d, seed=77, planted=X[::1000])
+    Q[-1] = X[999_999]; Q[-2] = X[0]                        # exact rows: must come back first
+    idx = DenseIndex(d, "bf16", capacity_hint=n); idx.append(X)
+    ids, sc, mn, mx = idx.search(Q, k)
+    assert ids[-1, 0] == 999_999 and ids[-2, 0] == 0
+    Xr, Qr = orc.bf16_round(X), orc.bf16_round(Q)
+    s32 = Qr @ Xr.T
+    ref_ids, _ = orc.topk_rule(s32, k)
+    for i in range(b):
+        if not np.array_equal(ids[i], ref_ids[i]):
+            cols = np.union1d(ids[i], ref_ids[i])
+            ex = np.full(n, -np.inf); ex[cols] = Qr[i].astype(np.float64) @ Xr[cols].astype(np.float64).T
+            orc.assert_topk_equivalent(ids[i], ref_ids[i], ex, ERR)
+        np.testing.assert_allclose(sc[i], s32[i][ids[i]], atol=ERR)
+    np.testing.assert_allclose(mx, s32.max(axis=1), atol=ERR)
+    np.testing.assert_allclose(mn, s32.min(axis=1), atol=ERR)
+    # |cos_bf16 - cos_fp32| <= 1e-3 (north_star tolerance) and recall@20 vs the fp32 reference ranking
+    s_fp32 = Q @ X.T
+    assert np.max(np.abs(np.take_along_axis(s_fp32, ids, 1) - sc)) <= 1e-3
+    ref32, _ = orc.topk_rule(s_fp32, k)
+    recall = np.mean([len(set(ids[i]) & set(ref32[i])) / k for i in range(b)])
+    assert recall >= 0.95, recall
+    # two logical shards merged == one index
+    h = n // 2
+    a = DenseIndex(d, "bf16", capacity_hint=h); a.append(X[:h])
+    c = DenseIndex(d, "bf16", capacity_hint=n - h); c.append(X[h:])
+    ia, sa, _, _ = a.search(Q, k); ic, sc2, _, _ = c.search(Q, k)
+    mi, ms = merge_topk(np.stack([ia, ic + h]), np.stack([sa, sc2]))
+    assert np.array_equal(mi, ids) and np.array_equal(ms, sc)
+    idx.close(); a.close(); c.close()
