@@ -72,11 +72,11 @@ struct DevBuf {
 struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf qfrag, lists, cnt, mm, part, flag;
+    DevBuf qfrag, lists, cnt, mm, part, flag, tau;
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
     void release() {
-        qfrag.release(); lists.release(); cnt.release(); mm.release(); part.release(); flag.release();
+        qfrag.release(); lists.release(); cnt.release(); mm.release(); part.release(); flag.release(); tau.release();
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
@@ -110,6 +110,7 @@ struct cmr_index {
     int force_ring = 0;      // CMR_SCAN_RING=8|16
     int force_asm = -1;      // CMR_SCAN_ASM_RING=0|1
     int force_grid = 0;      // CMR_SCAN_GRID
+    int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
 };
 
@@ -214,18 +215,49 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         if (rc) return rc;
         const int NQ = g.nqt * 32;
         const int W = g.grid * CMR_SCAN_WAVES;
-        const int lpg = 32;
-        const int G = (W + lpg - 1) / lpg;
+        // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
+        // best of that sample per query as the threshold of the next level / of the main scan.  Any
+        // subset's k-th best is a valid lower bound of the global k-th best, so results are unchanged;
+        // what changes is that only ~S_{i+1}*k/S_i scores per query ever reach the candidate lists
+        // (instead of k*ln(rows/k) per wave and query), which keeps every merge at a few thousand keys.
+        //   S0 = max(512, 32k) rows, S1 = clamp(N/32, 8*S0, 128*S0) rows (only when N >= 128 Ki rows)
+        long long level_panels[2] = {0, 0};
+        int n_levels = 0;
+        if (!idx->no_sample && npanels >= 256) {
+            const long long s0 = std::max<long long>(16, k);                       // panels
+            level_panels[n_levels++] = s0;
+            if (npanels >= 4096) {
+                const long long s1 = std::min<long long>(std::max<long long>(npanels / 32, 8 * s0), 128 * s0);
+                if (s1 < npanels / 2) level_panels[n_levels++] = s1;
+            }
+        }
+        long long max_sample = std::max(level_panels[0], level_panels[1]);
+        const int Ws = max_sample ? (int)((max_sample + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES : 0;
+        const int Wmax = std::max(W, Ws);
         HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
-        HIP_TRY(ws->lists.ensure((size_t)W * NQ * g.cap * 8));
-        HIP_TRY(ws->cnt.ensure((size_t)W * NQ * 4));
-        HIP_TRY(ws->mm.ensure((size_t)W * NQ * 8));
-        HIP_TRY(ws->part.ensure((size_t)nqp * G * k * 8));
+        HIP_TRY(ws->lists.ensure((size_t)Wmax * NQ * g.cap * 8));
+        HIP_TRY(ws->cnt.ensure((size_t)Wmax * NQ * 4));
+        HIP_TRY(ws->mm.ensure((size_t)Wmax * NQ * 8));
+        HIP_TRY(ws->tau.ensure((size_t)2 * NQ * 8));
         HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev + (size_t)q0 * idx->dim, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p,
                                         (int*)ws->flag.p, s));
         CmrScanArgs a{};
         a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
         a.lists = (u64*)ws->lists.p; a.cnt = (int*)ws->cnt.p; a.mm = (float2*)ws->mm.p;
+        if (n_levels) HIP_TRY(hipMemsetAsync(ws->tau.p, 0, (size_t)2 * NQ * 8, s));
+        for (int lv = 0; lv < n_levels; ++lv) {
+            const long long sp = level_panels[lv];
+            const int Wl = (int)((sp + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES;
+            CmrScanGeom gs = g;
+            gs.grid = Wl / CMR_SCAN_WAVES;
+            CmrScanArgs as = a;
+            as.sample_waves = (int)sp; as.sample_stride = (int)(npanels / sp);
+            u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
+            HIP_TRY(cmr_launch_scan_topk(gs, as, s));
+            HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
+                                           nullptr, nullptr, nullptr, tau_out, s));
+            a.tau_init = tau_out;
+        }
         ProfEvent pe{};
         bool prof = false;
         {
@@ -244,10 +276,9 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
             idx->prof_events.push_back(pe);
             idx->prof_bytes = algorithmic_bytes(idx, nqp, k);
         }
-        HIP_TRY(cmr_launch_merge_lists((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, lpg, (u64*)ws->part.p, s));
-        HIP_TRY(cmr_launch_final_topk((const u64*)ws->part.p, G, nqp, k, (const float2*)ws->mm.p, W, NQ, 0,
-                                      ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k,
-                                      min_dev ? min_dev + q0 : nullptr, max_dev ? max_dev + q0 : nullptr, s));
+        HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, (const float2*)ws->mm.p, 0,
+                                       ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k,
+                                       min_dev ? min_dev + q0 : nullptr, max_dev ? max_dev + q0 : nullptr, nullptr, s));
     }
     return CMR_OK;
 }
@@ -370,6 +401,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_ring = env_int("CMR_SCAN_RING", 0);
     idx->force_asm = env_int("CMR_SCAN_ASM_RING", -1);
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
+    idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);

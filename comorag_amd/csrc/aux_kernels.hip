@@ -118,95 +118,189 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 }
 
 // ------------------------------------------------------------------------------------------
-// Stage A of the candidate merge: (query q, group g of `lpg` wave lists) -> k best keys.
-__global__ __launch_bounds__(256) void merge_lists_kernel(const u64* __restrict__ lists, const int* __restrict__ cnt, int W,
-                                                          int nq_stride, int cap, int k, int lpg, u64* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    u64* pool = reinterpret_cast<u64*>(sm);                    // lpg*cap keys
-    u64* wbest = pool + (size_t)lpg * cap;                     // 4
-    int* offs = reinterpret_cast<int*>(wbest + 4);             // lpg+1
-    const int q = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+// Candidate merge: ONE workgroup (256 threads, one wave per SIMD) per query gathers the W per-wave lists of the
+// scan (sparse: the sampling threshold keeps them at a few entries each) and selects the k best
+// keys.  The concatenated lists are consumed in chunks of 4096 keys held in registers (16 per
+// thread) with the running top-k carried over, so any total (up to W*cap) is handled; the common
+// case is a single chunk.
+//   sample pass (out_tau != nullptr): publishes (k-th best key) - 1 as the main scan's threshold
+//   main pass: writes ids/scores (+ id_base) and reduces the per-wave min/max partials.
+#define MERGE_THREADS 256
+#define MERGE_WAVES 4
+
+// One selection pass: every thread holds up to MERGE_PER_THREAD (+1 carried) keys in registers;
+// k rounds of {thread max, wave max (shuffles), block max via LDS} extract the k best in
+// descending order.  One barrier per round (wbest is double buffered).  Keys are unique, so
+// exactly one register in the block equals each round's winner.
+#define MERGE_PER_THREAD 16
+#define MERGE_POOL (MERGE_THREADS * MERGE_PER_THREAD)
+
+// max of a u64 over the 64 lanes, uniform result.  DPP butterflies inside each row of 16 lanes
+// (quad_perm xor1, xor2, row_half_mirror, row_mirror), then 4 readlanes — no LDS traffic.
+__device__ __forceinline__ u64 cmr_wave_max_u64(u64 v) {
+#define CMR_DPP_MAX(ctrl)                                                                                 \
+    {                                                                                                     \
+        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), ctrl, 0xF, 0xF, true); \
+        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, ctrl, 0xF, 0xF, true); \
+        const u64 o = ((u64)ohi << 32) | olo;                                                             \
+        v = o > v ? o : v;                                                                                \
+    }
+    CMR_DPP_MAX(0xB1)    // quad_perm:[1,0,3,2]
+    CMR_DPP_MAX(0x4E)    // quad_perm:[2,3,0,1]
+    CMR_DPP_MAX(0x141)   // row_half_mirror
+    CMR_DPP_MAX(0x140)   // row_mirror
+#undef CMR_DPP_MAX
+    u64 r = 0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), row * 16);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, row * 16);
+        const u64 x = ((u64)hi << 32) | lo;
+        r = x > r ? x : r;
+    }
+    return r;
+}
+
+__device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1], int k, u64* wbest, u64* res) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int w0 = g * lpg;
-    const int nl = min(lpg, W - w0);
-    if (tid == 0) {
-        int o = 0;
-        for (int l = 0; l < nl; ++l) {
-            offs[l] = o;
-            int c = cnt[(size_t)(w0 + l) * nq_stride + q];
-            o += c < cap ? c : cap;
+    for (int round = 0; round < k; ++round) {
+        u64 best = e[0];
+#pragma unroll
+        for (int j = 1; j <= MERGE_PER_THREAD; ++j) best = e[j] > best ? e[j] : best;
+        const u64 wb = cmr_wave_max_u64(best);
+        u64* wbuf = wbest + (round & 1) * MERGE_WAVES;
+        if (lane == 0) wbuf[wave] = wb;
+        __syncthreads();
+        const u64 fb = cmr_wave_max_u64(lane < MERGE_WAVES ? wbuf[lane] : 0ull);
+        if (tid == 0) res[round] = fb;
+        if (fb == 0) {   // fewer than k keys in total: the rest of res stays zero (uniform exit)
+            for (int r = round + 1 + tid; r < k; r += MERGE_THREADS) res[r] = 0;
+            break;
         }
-        offs[nl] = o;
+#pragma unroll
+        for (int j = 0; j <= MERGE_PER_THREAD; ++j) e[j] = (e[j] == fb) ? 0ull : e[j];
     }
     __syncthreads();
-    for (int l = wave; l < nl; l += 4) {
-        const int c = offs[l + 1] - offs[l];
-        const u64* L = lists + ((size_t)(w0 + l) * nq_stride + q) * cap;
-        for (int i = lane; i < c; i += 64) pool[offs[l] + i] = L[i];
-    }
-    __syncthreads();
-    cmr_block_select(pool, offs[nl], k, part + ((size_t)q * G + g) * k, wbest);
 }
 
-hipError_t cmr_launch_merge_lists(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
-                                  int lpg, u64* part, hipStream_t s) {
-    const int G = (W + lpg - 1) / lpg;
-    const size_t lds = (size_t)lpg * cap * 8 + 4 * 8 + (size_t)(lpg + 1) * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_lists_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(merge_lists_kernel, dim3(nq, G), dim3(256), lds, s, lists, cnt, W, nq_stride, cap, k, lpg, part);
-    return hipGetLastError();
-}
-
-// Stage B: part[q][G][k] -> final ids/scores, plus min/max over the W waves' partials.
-__global__ __launch_bounds__(256) void final_topk_kernel(const u64* __restrict__ part, int G, int k, const float2* __restrict__ mm,
-                                                         int W, int nq_stride, long long id_base, int64_t* __restrict__ out_ids,
-                                                         float* __restrict__ out_scores, float* __restrict__ out_min,
-                                                         float* __restrict__ out_max) {
+__global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* __restrict__ lists, const int* __restrict__ cnt,
+                                                                    int W, int nq_stride, int cap, int k,
+                                                                    const float2* __restrict__ mm, long long id_base,
+                                                                    int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                                    float* __restrict__ out_min, float* __restrict__ out_max,
+                                                                    u64* __restrict__ out_tau) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    u64* pool = reinterpret_cast<u64*>(sm);          // G*k
-    u64* wbest = pool + (size_t)G * k;               // 4
-    u64* res = wbest + 4;                            // k
-    float* red = reinterpret_cast<float*>(res + k);  // 8
+    u64* wbest = reinterpret_cast<u64*>(sm);                // 2*MERGE_WAVES
+    u64* res = wbest + 2 * MERGE_WAVES;                     // k
+    int* prefix = reinterpret_cast<int*>(res + k);          // W+1
+    int* wsum = prefix + (W + 1);                           // MERGE_WAVES
+    float* red = reinterpret_cast<float*>(wsum + MERGE_WAVES);  // 2*MERGE_WAVES
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = G * k;
-    for (int i = tid; i < n; i += 256) pool[i] = part[(size_t)q * n + i];
+
+    // exclusive prefix sum of the W list lengths
+    const int CH = (W + MERGE_THREADS - 1) / MERGE_THREADS;
+    int c[16];
+    int local = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) c[j] = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= CH) break;
+        const int w = tid * CH + j;
+        if (w < W) { int v = cnt[(size_t)w * nq_stride + q]; c[j] = v < cap ? v : cap; }
+        local += c[j];
+    }
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    cmr_block_select(pool, n, k, res, wbest);
-    for (int i = tid; i < k; i += 256) {
+    int wbase = 0;
+    for (int w2 = 0; w2 < wave; ++w2) wbase += wsum[w2];
+    int run = wbase + incl - local;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j >= CH) break;
+        const int w = tid * CH + j;
+        if (w < W) prefix[w] = run;
+        run += c[j];
+    }
+    if (tid == MERGE_THREADS - 1) prefix[W] = run;
+    for (int i = tid; i < k; i += MERGE_THREADS) res[i] = 0;
+    __syncthreads();
+
+    // Chunks of MERGE_POOL elements of the concatenated lists, gathered straight into registers
+    // (binary search of the prefix array per element: 16 independent searches per thread); the
+    // running top-k is carried in the 17th register slot of the first k threads.
+    const int total = prefix[W];
+    int base = 0;
+    do {
+        u64 e[MERGE_PER_THREAD + 1];
+        e[MERGE_PER_THREAD] = (base > 0 && tid < k) ? res[tid] : 0ull;
+        // 16 branch-free binary searches advanced in lock step (independent LDS reads per step),
+        // then all 16 global loads issued back to back.
+        int pos[MERGE_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < MERGE_PER_THREAD; ++j) pos[j] = 0;
+        for (int step = 2048; step > 0; step >>= 1) {        // W <= 4096 lists
+#pragma unroll
+            for (int j = 0; j < MERGE_PER_THREAD; ++j) {
+                const int v = base + tid + MERGE_THREADS * j;
+                const int np = pos[j] + step;
+                const int pv = prefix[np < W ? np : W];      // prefix[W] = total > any valid v
+                pos[j] = (np < W && pv <= v) ? np : pos[j];  // largest w with prefix[w] <= v
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MERGE_PER_THREAD; ++j) {
+            const int v = base + tid + MERGE_THREADS * j;
+            const int w = pos[j];
+            const size_t off = ((size_t)w * nq_stride + q) * cap + (size_t)(v < total ? v - prefix[w] : 0);
+            const u64 key = lists[off];                      // always in bounds; masked below
+            e[j] = v < total ? key : 0ull;
+        }
+        __syncthreads();     // every thread has read its carried key before the rounds rewrite res
+        merge_select_regs(e, k, wbest, res);
+        base += MERGE_POOL;
+    } while (base < total);
+
+    if (out_tau) {
+        if (tid == 0) out_tau[q] = res[k - 1] ? res[k - 1] - 1 : 0ull;
+        return;
+    }
+    for (int i = tid; i < k; i += MERGE_THREADS) {
         const u64 key = res[i];
         out_ids[(size_t)q * k + i] = key ? (int64_t)cmr_key_row(key) + id_base : -1;
         out_scores[(size_t)q * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
     }
     if (out_min || out_max) {
         float mn = __builtin_inff(), mx = -__builtin_inff();
-        for (int w = tid; w < W; w += 256) {
+        for (int w = tid; w < W; w += MERGE_THREADS) {
             const float2 v = mm[(size_t)w * nq_stride + q];
             mn = fminf(mn, v.x); mx = fmaxf(mx, v.y);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
-        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+        if (lane == 0) { red[wave] = mn; red[MERGE_WAVES + wave] = mx; }
         __syncthreads();
         if (tid == 0) {
-            mn = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
-            mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+            for (int w2 = 1; w2 < MERGE_WAVES; ++w2) { mn = fminf(mn, red[w2]); mx = fmaxf(mx, red[MERGE_WAVES + w2]); }
             if (out_min) out_min[q] = mn;
             if (out_max) out_max[q] = mx;
         }
     }
 }
 
-hipError_t cmr_launch_final_topk(const u64* part, int G, int nq, int k, const float2* mm, int W, int nq_stride,
-                                 long long id_base, int64_t* out_ids, float* out_scores, float* out_min,
-                                 float* out_max, hipStream_t s) {
-    const size_t lds = ((size_t)G * k + 4 + k) * 8 + 8 * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(final_topk_kernel),
+hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
+                                  const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
+                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s) {
+    if (W > 16 * MERGE_THREADS) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)2 * MERGE_WAVES + k) * 8 + (size_t)(W + 1) * 4 + MERGE_WAVES * 4 + 2 * MERGE_WAVES * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_query_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(final_topk_kernel, dim3(nq), dim3(256), lds, s, part, G, k, mm, W, nq_stride, id_base, out_ids,
-                       out_scores, out_min, out_max);
+    hipLaunchKernelGGL(merge_query_kernel, dim3(nq), dim3(MERGE_THREADS), lds, s, lists, cnt, W, nq_stride, cap, k, mm, id_base,
+                       out_ids, out_scores, out_min, out_max, out_tau);
     return hipGetLastError();
 }
 

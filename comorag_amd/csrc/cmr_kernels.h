@@ -37,6 +37,10 @@ struct CmrScanArgs {
     float* scores;        // [nq][ld]
     long long ld;
     int nq;
+    // sampling pass (top-k mode): wave w < sample_waves scans panel w*sample_stride only
+    int sample_waves;
+    int sample_stride;
+    const u64* tau_init;  // [nqt*32] initial threshold keys or nullptr
 };
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
@@ -49,13 +53,10 @@ hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, i
 hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, int dim, int dpad,
                                    long long row0, void* corpus, float* shadow, int* nonfinite_flag,
                                    hipStream_t s);
-// per-wave lists -> per-group top-k keys: part[q][G][k]
-hipError_t cmr_launch_merge_lists(const u64* lists, const int* cnt, int W, int nq_stride, int cap,
-                                  int nq, int k, int lists_per_group, u64* part, hipStream_t s);
-// part[q][G][k] -> ids/scores (+ min/max over W waves)
-hipError_t cmr_launch_final_topk(const u64* part, int G, int nq, int k, const float2* mm, int W,
-                                 int nq_stride, long long id_base, int64_t* out_ids, float* out_scores,
-                                 float* out_min, float* out_max, hipStream_t s);
+// per-wave candidate lists -> per-query top-k (ids/scores + min/max), or the sampling threshold
+hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
+                                  const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
+                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s);
 // shard merge: ids/scores [S][nq][k] -> [nq][k]
 hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int S, int nq, int k,
                                    int64_t* out_ids, float* out_scores, hipStream_t s);

@@ -41,6 +41,9 @@ struct ScanP {
     float* scores;
     long long ld;
     int nq;
+    int sample_waves;      // > 0: sampling pass — wave w (< sample_waves) scans the single panel w*sample_stride
+    int sample_stride;
+    const u64* tau_init;   // per-query initial threshold keys (from the sampling pass) or nullptr
 };
 
 template <int CAP>
@@ -123,8 +126,14 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
 
     const int W = gridDim.x * CMR_SCAN_WAVES;
     const int gw = blockIdx.x * CMR_SCAN_WAVES + wave;
-    const int p0 = (int)(((long long)gw * P.npanels) / W);
-    const int p1 = (int)(((long long)(gw + 1) * P.npanels) / W);
+    int p0, p1;
+    if (P.sample_waves > 0) {   // sampling pass: one strided panel per wave
+        p0 = gw * P.sample_stride;
+        p1 = gw < P.sample_waves ? p0 + 1 : p0;
+    } else {
+        p0 = (int)(((long long)gw * P.npanels) / W);
+        p1 = (int)(((long long)(gw + 1) * P.npanels) / W);
+    }
 
     float rmin[NQT], rmax[NQT], tau_f[NQT];
     u64 tau_key[NQT];
@@ -134,6 +143,10 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         rmax[t] = -__builtin_inff();
         tau_f[t] = -__builtin_inff();
         tau_key[t] = 0ull;
+        if (MODE == MODE_TOPK && P.tau_init) {   // a valid lower bound on the global k-th best key
+            tau_key[t] = P.tau_init[t * 32 + (lane & 31)];
+            if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
+        }
     }
     u64* list_w = (MODE == MODE_TOPK) ? P.lists + (size_t)gw * NQ * CAP : nullptr;
 
@@ -314,10 +327,10 @@ static hipError_t dispatch(const CmrScanGeom& g, const ScanP& p, hipStream_t s) 
     if (g.nqt == NQT && g.cap == CAP && g.ring == R) return launch_one<DT, NQT, CAP, R, MODE>(g, p, s);
     if constexpr (MODE == MODE_TOPK) {
         CASE(1, 128, 8) CASE(1, 128, 16) CASE(1, 256, 8) CASE(1, 256, 16)
-        if constexpr (DT != CMR_DT_F32) { CASE(2, 128, 8) CASE(2, 128, 16) CASE(2, 256, 8) CASE(2, 256, 16) }
+        CASE(2, 128, 8) CASE(2, 128, 16) CASE(2, 256, 8) CASE(2, 256, 16)
     } else {
         CASE(1, 128, 8) CASE(1, 128, 16)
-        if constexpr (DT != CMR_DT_F32) { CASE(2, 128, 8) CASE(2, 128, 16) }
+        CASE(2, 128, 8) CASE(2, 128, 16)
     }
 #undef CASE
     return hipErrorInvalidValue;
@@ -330,6 +343,7 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.nrows = a.nrows; p.npanels = a.npanels; p.ks = g.ks; p.k = a.k;
     p.lists = a.lists; p.cnt = a.cnt; p.mm = a.mm;
     p.scores = a.scores; p.ld = a.ld; p.nq = a.nq;
+    p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.tau_init = a.tau_init;
     return p;
 }
 

@@ -82,35 +82,48 @@ class ShardedIndex:
         return self._bufs[key]
 
     def search_pipelined(self, q_t, k: int, slot: int):
-        """Enqueue one batch: scan on the current stream, all-gather + merge on a side stream.
-        Results (global ids / scores, torch CUDA tensors) are valid after `bufs['done']`.
-        Alternate `slot` (0/1) between consecutive batches."""
+        """Enqueue one batch without blocking the host.  Buffers are double buffered (`slot` 0/1,
+        alternate between consecutive batches):
+          scan stream : query packing, sampling passes, the corpus scan, per-shard candidate merge
+          side stream : RCCL all-gather of the [B,k] candidates + final shard merge (per slot)
+        so the latency-bound collective + shard merge of batch i overlap the HBM-bound scan of
+        batch i+1.  Returns the slot's buffer dict; `o_ids`/`o_sc` (global ids / raw scores) are
+        valid after `bufs['done']` (a torch.cuda.Event)."""
         import ctypes as C
         import torch
         import torch.distributed as dist
         dev = q_t.device
         nq = q_t.shape[0]
         b = self._buffers(slot, nq, k, dev)
-        main = torch.cuda.current_stream(dev)
+        caller = torch.cuda.current_stream(dev)
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+            # ONE scan stream: two HBM-bound scans in flight at once only slow each other down
+            # (measured: 2-stream scans 0.68 ms/step vs 0.43 ms/step serial at 1 M rows).
+            sc = torch.cuda.Stream(device=dev)
+            self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            self._scan = [sc, sc]
+        scan, side = self._scan[slot], self._side[slot]
+        ready = torch.cuda.Event()
+        ready.record(caller)                      # q_t produced on the caller's stream
+        scan.wait_event(ready)
         if b["used"]:
-            main.wait_event(b["done"])            # slot reuse: previous merge of this slot finished
-        self.local.search_dev(q_t, k, out_ids=b["ids"], out_scores=b["sc"])
-        if self.base:
-            b["ids"].add_(self.base * (b["ids"] >= 0))
-        b["scanned"].record(main)
-        with torch.cuda.stream(self._side):
-            self._side.wait_event(b["scanned"])
+            scan.wait_event(b["done"])            # slot reuse: its previous merge has consumed ids/sc
+        with torch.cuda.stream(scan):
+            self.local.search_dev(q_t, k, out_ids=b["ids"], out_scores=b["sc"], stream=scan.cuda_stream)
+            if self.base:
+                b["ids"].add_(self.base * (b["ids"] >= 0))
+            b["scanned"].record(scan)
+        with torch.cuda.stream(side):
+            side.wait_event(b["scanned"])
             if self.world > 1:
                 dist.all_gather_into_tensor(b["g_ids"], b["ids"], group=self.group)
                 dist.all_gather_into_tensor(b["g_sc"], b["sc"], group=self.group)
                 L.check(L.lib().cmr_merge_topk_dev(
                     self.device, C.c_void_p(b["g_ids"].data_ptr()), C.c_void_p(b["g_sc"].data_ptr()), self.world, nq, k,
-                    C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), C.c_void_p(self._side.cuda_stream)))
+                    C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), C.c_void_p(side.cuda_stream)))
             else:
                 b["o_ids"].copy_(b["ids"], non_blocking=True)
                 b["o_sc"].copy_(b["sc"], non_blocking=True)
-            b["done"].record(self._side)
+            b["done"].record(side)
         b["used"] = True
         return b
