@@ -1,0 +1,167 @@
+"""HipBGEEmbeddingModel — drop-in for BGEEmbeddingModel (src/comorag/embedding_model/BGEEmbedding.py).
+
+tokenise (HF tokenizers, host threads) → encoder forward (PyTorch-ROCm) → fused masked mean-pool +
+L2-normalise as ONE HIP kernel pair on the encoder's output tensor (`cmr_pool_l2norm`; replaces
+`mean_pooling` :15-28 and `F.normalize` :126-127).  Call surface, argument handling and quirks follow
+the reference:
+  * `batch_encode` ALWAYS overwrites `instruction` with the fixed BGE prefix because callers never
+    pass `is_query` (:150-155), so `instruction=` / `norm=` passed by ComoRAG are ignored — kept;
+  * prefix + text are concatenated with no separator (:109);
+  * `encode(list)` positional returns a torch tensor [n, D] (memory_utils.py:176,205,297 index it).
+Fixed consciously: `max_length` is clamped to the model's `max_position_embeddings` (the reference
+default 2048 overflows BERT's 512 positions), `embedding_model_dtype` is honoured, and
+tokenisation of mini-batch i+1 overlaps the forward of mini-batch i.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+from copy import deepcopy
+from typing import List, Optional, Union
+
+import numpy as np
+
+from .. import _lib as L
+from ..utils.config_utils import BaseConfig, cfg_get
+from .base import BaseEmbeddingModel, EmbeddingConfig, make_cache_embed
+
+BGE_PREFIX = "Generate a representation for this sentence to retrieve relevant articles:"
+_TORCH_TO_CMR = {"torch.float32": L.CMR_F32, "torch.bfloat16": L.CMR_BF16, "torch.float16": L.CMR_F16}
+
+
+def pool_l2norm(hidden, mask, normalize: bool = True):
+    """hidden [b,l,d] (fp32/bf16/fp16, CUDA, contiguous), mask [b,l] int64 → torch fp32 [b,d] on the
+    same device, on torch's current stream.  Raises without a GPU: there is no CPU fallback."""
+    import torch
+    if not hidden.is_cuda:
+        raise RuntimeError("pool_l2norm needs CUDA tensors: comorag_amd has no CPU fallback")
+    hidden = hidden.contiguous()
+    mask = mask.to(device=hidden.device, dtype=torch.int64).contiguous()
+    b, l, d = hidden.shape
+    out = torch.empty((b, d), dtype=torch.float32, device=hidden.device)
+    stream = torch.cuda.current_stream(hidden.device).cuda_stream
+    L.check(L.lib().cmr_pool_l2norm(hidden.device.index or 0, C.c_void_p(hidden.data_ptr()), _TORCH_TO_CMR[str(hidden.dtype)],
+                                    C.c_void_p(mask.data_ptr()), b, l, d, 1 if normalize else 0,
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+    return out
+
+
+class HipBGEEmbeddingModel(BaseEmbeddingModel):
+    def __init__(self, global_config: Optional[BaseConfig] = None, embedding_model_name: Optional[str] = None,
+                 model=None, tokenizer=None) -> None:
+        """`model` / `tokenizer` may be injected (tests use a seed-initialised BertModel and a synthetic
+        WordPiece vocabulary: no BGE weights exist offline); otherwise HF `from_pretrained` as the
+        reference (:51-52)."""
+        super().__init__(global_config=global_config)
+        if embedding_model_name is not None:
+            self.embedding_model_name = embedding_model_name
+        self._init_embedding_config()
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBGEEmbeddingModel needs an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", int(cfg_get(self.global_config, "device", 0)))
+        if tokenizer is None or model is None:
+            from transformers import AutoModel, AutoTokenizer
+            tokenizer = tokenizer or AutoTokenizer.from_pretrained(self.embedding_model_name)
+            model = model or AutoModel.from_pretrained(self.embedding_model_name, trust_remote_code=True)
+        dt = str(cfg_get(self.global_config, "embedding_model_dtype", "auto")).lower()
+        tdt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
+               "f16": torch.float16}.get(dt)
+        self.tokenizer = tokenizer
+        self.embedding_model = model.to(self.device) if tdt is None else model.to(self.device, dtype=tdt)
+        self.embedding_model.eval()
+        self.embedding_dim = self.embedding_model.config.hidden_size
+        self.max_positions = int(getattr(self.embedding_model.config, "max_position_embeddings", 1 << 30))
+        self._tok_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cmr-tok")
+        if cfg_get(self.global_config, "embedding_cache_enabled", False):
+            path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
+            self.encode = make_cache_embed(self._encode, path, self.device)
+        else:
+            self.encode = self._encode
+
+    def _init_embedding_config(self) -> None:
+        self.embedding_config = EmbeddingConfig.from_dict({
+            "embedding_model_name": self.embedding_model_name,
+            "norm": cfg_get(self.global_config, "embedding_return_as_normalized", True),
+            "model_init_params": {"pretrained_model_name_or_path": self.embedding_model_name, "trust_remote_code": True,
+                                  "device_map": "auto"},
+            "encode_params": {"max_length": cfg_get(self.global_config, "embedding_max_seq_len", 2048),
+                              "query_instruction": BGE_PREFIX, "passage_instruction": BGE_PREFIX,
+                              "batch_size": cfg_get(self.global_config, "embedding_batch_size", 32), "num_workers": 32},
+        })
+
+    # ------------------------------------------------------------------ one mini-batch
+    def _tokenize(self, prompts: List[str], max_length: int):
+        return self.tokenizer(prompts, padding=True, truncation=True,
+                              max_length=min(int(max_length), self.max_positions), return_tensors="pt")
+
+    def _forward_pool(self, inputs, normalize: bool):
+        import torch
+        with torch.no_grad():
+            inputs = {k: v.to(self.device, non_blocking=True) for k, v in inputs.items()}
+            hidden = self.embedding_model(**inputs).last_hidden_state
+            return pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize)
+
+    def _encode(self, prompts: Union[str, List[str]], **kwargs):
+        """BGEEmbedding.py:92-129 for one mini-batch; returns a torch fp32 tensor [b, D] on the GPU."""
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        instruction = kwargs.get("instruction", "")
+        if instruction:
+            prompts = [instruction + text for text in prompts]
+        max_length = kwargs.get("max_length", self.embedding_config.encode_params.get("max_length", 512))
+        return self._forward_pool(self._tokenize(prompts, max_length), kwargs.get("normalize", True))
+
+    # ------------------------------------------------------------------ public
+    def batch_encode(self, texts: Union[str, List[str]], **kwargs) -> np.ndarray:
+        """BGEEmbedding.py:131-185.  Returns np.ndarray [n, D] fp32, rows L2-normalised."""
+        import torch
+        if isinstance(texts, str):
+            texts = [texts]
+        params = deepcopy(self.embedding_config.encode_params)
+        if kwargs:
+            params.update(kwargs)
+        if "is_query" in kwargs and kwargs["is_query"]:
+            params["instruction"] = params.get("query_instruction", BGE_PREFIX)
+        else:
+            params["instruction"] = params.get("passage_instruction", BGE_PREFIX)
+        batch_size = params.pop("batch_size", 16)
+        if len(texts) <= batch_size or self.encode is not self._encode:
+            if len(texts) <= batch_size:
+                params["prompts"] = texts
+                results = self.encode(**params)
+            else:  # cached encoder: keep the reference's simple loop
+                parts = []
+                for i in range(0, len(texts), batch_size):
+                    params["prompts"] = texts[i:i + batch_size]
+                    parts.append(self.encode(**params))
+                results = torch.cat(parts, dim=0)
+        else:
+            # same mini-batches as the reference loop (:168-175); tokenisation of batch i+1 runs on a
+            # host thread while batch i is on the GPU
+            instr = params.get("instruction", "")
+            max_length = params.get("max_length", 512)
+            normalize = params.get("normalize", True)
+            chunks = [texts[i:i + batch_size] for i in range(0, len(texts), batch_size)]
+            prep = lambda c: self._tokenize([instr + t for t in c] if instr else list(c), max_length)
+            fut = self._tok_pool.submit(prep, chunks[0])
+            parts = []
+            for i in range(len(chunks)):
+                inputs = fut.result()
+                if i + 1 < len(chunks):
+                    fut = self._tok_pool.submit(prep, chunks[i + 1])
+                parts.append(self._forward_pool(inputs, normalize))
+            results = torch.cat(parts, dim=0)
+        if isinstance(results, torch.Tensor):
+            results = results.float().cpu().numpy()
+        if self.embedding_config.norm and not kwargs.get("normalize", True):
+            results = (results.T / np.linalg.norm(results, axis=1)).T
+        return results
+
+    def encode_queries(self, queries, **kwargs) -> np.ndarray:
+        kwargs["is_query"] = True
+        return self.batch_encode(queries, **kwargs)
+
+    def encode_passages(self, passages, **kwargs) -> np.ndarray:
+        kwargs["is_query"] = False
+        return self.batch_encode(passages, **kwargs)

@@ -1,0 +1,229 @@
+"""EmbeddingStore — drop-in for src/comorag/embedding_store.py:13-167 with an HBM-resident mirror.
+
+Same constructor, methods, attributes and return values as the reference class (the fixtures in
+tests/golden/store.json were produced by the reference and are replayed against this class), so
+ComoRAG.py / timeline_utils.py / cluster_utils.py run on it unchanged.  What differs underneath:
+
+* rows live in ONE growable fp32 matrix (amortised doubling) instead of a Python list of arrays:
+  `get_embeddings` gathers rows without first copying all N rows (reference :150-157);
+* the parquet file keeps the reference schema {hash_id: str, content: str, embedding: list<float>}
+  and is written straight from the matrix with pyarrow (no per-row Python objects);
+* `device_index()` lazily builds, and `insert_strings` then keeps appending to, a `DenseIndex`
+  (MFMA-fragment-major panels in HBM) whose row ids equal `hash_id_to_idx` — the retrieval hooks
+  (comorag_amd/hooks.py) search it instead of re-materialising host matrices.
+
+Conscious deviations: `hash_id_to_text` / `text_to_hash_id` exist on an empty store too (the
+reference leaves them undefined until the first save, embedding_store.py:106-107).
+"""
+from __future__ import annotations
+
+import logging
+import os
+import threading
+from copy import deepcopy
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from .utils.misc_utils import compute_mdhash_id
+
+logger = logging.getLogger(__name__)
+
+
+class _RowList:
+    """List-like view of the store's matrix rows (the reference exposes `embeddings` as a list of
+    ndarrays; callers index, iterate and len() it)."""
+
+    def __init__(self, store):
+        self._s = store
+
+    def __len__(self):
+        return self._s._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._s._mat[j] for j in range(*i.indices(self._s._n))]
+        if i < 0:
+            i += self._s._n
+        if not 0 <= i < self._s._n:
+            raise IndexError(i)
+        return self._s._mat[i]
+
+    def __iter__(self):
+        for i in range(self._s._n):
+            yield self._s._mat[i]
+
+
+class EmbeddingStore:
+    def __init__(self, embedding_model, db_filename, batch_size, namespace):
+        self.embedding_model = embedding_model
+        self.batch_size = batch_size
+        self.namespace = namespace
+        if not os.path.exists(db_filename):
+            logger.info(f"Creating working directory: {db_filename}")
+            os.makedirs(db_filename, exist_ok=True)
+        self.filename = os.path.join(db_filename, f"vdb_{self.namespace}.parquet")
+        self._lock = threading.RLock()
+        self._mat = np.empty((0, 0), dtype=np.float32)
+        self._n = 0
+        self._src_dtype = np.float32          # dtype the encoder handed over (persisted as is)
+        self._index = None
+        self._index_kw: dict = {}
+        self._load_data()
+
+    # ------------------------------------------------------------------ storage
+    @property
+    def embeddings(self):
+        return _RowList(self)
+
+    def _reserve(self, extra: int, dim: int) -> None:
+        if self._mat.shape[1] != dim:
+            if self._n:
+                raise ValueError(f"embedding dim changed: {self._mat.shape[1]} -> {dim}")
+            self._mat = np.empty((max(extra, 16), dim), dtype=np.float32)
+        if self._n + extra > self._mat.shape[0]:
+            cap = max(self._n + extra, 2 * self._mat.shape[0], 16)
+            new = np.empty((cap, dim), dtype=np.float32)
+            new[:self._n] = self._mat[:self._n]
+            self._mat = new
+
+    def _rebuild_maps(self) -> None:
+        self.hash_id_to_idx = {h: idx for idx, h in enumerate(self.hash_ids)}
+        self.hash_id_to_row = {h: {"hash_id": h, "content": t} for h, t in zip(self.hash_ids, self.texts)}
+        self.hash_id_to_text = {h: t for h, t in zip(self.hash_ids, self.texts)}
+        self.text_to_hash_id = {t: h for h, t in zip(self.hash_ids, self.texts)}
+
+    def _load_data(self):
+        """embedding_store.py:92-107.  Reads files written by the reference or by this class."""
+        self.hash_ids, self.texts = [], []
+        if os.path.exists(self.filename):
+            import pyarrow.parquet as pq
+            t = pq.read_table(self.filename, columns=["hash_id", "content", "embedding"])
+            self.hash_ids = t.column("hash_id").to_pylist()
+            self.texts = t.column("content").to_pylist()
+            col = t.column("embedding").combine_chunks()
+            n = len(self.hash_ids)
+            if n:
+                flat = col.flatten().to_numpy(zero_copy_only=False)
+                self._src_dtype = flat.dtype
+                dim = len(flat) // n
+                assert dim * n == len(flat), "ragged embedding column"
+                self._reserve(n, dim)
+                self._mat[:n] = flat.reshape(n, dim).astype(np.float32, copy=False)
+                self._n = n
+            assert len(self.hash_ids) == len(self.texts) == self._n
+            logger.info(f"Loaded {len(self.hash_ids)} records from {self.filename}")
+        self._rebuild_maps()
+
+    def _save_data(self):
+        """embedding_store.py:109-120 — same file name and schema, whole-file rewrite."""
+        import pyarrow as pa
+        import pyarrow.parquet as pq
+        n, dim = self._n, (self._mat.shape[1] if self._n else 0)
+        values = pa.array(np.ascontiguousarray(self._mat[:n]).reshape(-1).astype(self._src_dtype, copy=False))
+        offsets = pa.array(np.arange(0, (n + 1) * dim, dim, dtype=np.int32) if dim else np.zeros(n + 1, np.int32))
+        emb = pa.ListArray.from_arrays(offsets, values)
+        table = pa.table({"hash_id": pa.array(self.hash_ids, type=pa.string()),
+                          "content": pa.array(self.texts, type=pa.string()), "embedding": emb})
+        tmp = self.filename + ".tmp"
+        pq.write_table(table, tmp)
+        os.replace(tmp, self.filename)
+        self._rebuild_maps()
+        logger.info(f"Saved {len(self.hash_ids)} records to {self.filename}")
+
+    def _upsert(self, hash_ids, texts, embeddings):
+        emb = np.asarray(embeddings)
+        if emb.ndim == 1:
+            emb = emb[None, :]
+        if self._n == 0:
+            self._src_dtype = emb.dtype if emb.dtype in (np.float32, np.float64) else np.float32
+        self._reserve(len(hash_ids), emb.shape[1])
+        self._mat[self._n:self._n + len(hash_ids)] = emb
+        new_rows = self._mat[self._n:self._n + len(hash_ids)]
+        self._n += len(hash_ids)
+        self.hash_ids.extend(hash_ids)
+        self.texts.extend(texts)
+        if self._index is not None:
+            self._index.append(new_rows)
+        logger.info("Saving new records.")
+        self._save_data()
+
+    # ------------------------------------------------------------------ reference API
+    def get_missing_string_hash_ids(self, texts: List[str]):
+        nodes_dict = {}
+        for text in texts:
+            nodes_dict[compute_mdhash_id(text, prefix=self.namespace + "-")] = {"content": text}
+        all_hash_ids = list(nodes_dict.keys())
+        if not all_hash_ids:
+            return {}
+        existing = self.hash_id_to_row.keys()
+        missing_ids = [h for h in all_hash_ids if h not in existing]
+        texts_to_encode = [nodes_dict[h]["content"] for h in missing_ids]
+        return {h: {"hash_id": h, "content": t} for h, t in zip(missing_ids, texts_to_encode)}
+
+    def insert_strings(self, texts: List[str]):
+        """embedding_store.py:63-90: dict-dedup (first occurrence keeps its slot), skip known ids,
+        ONE batch_encode call for the missing texts, upsert.  Returns None / {} like the reference."""
+        with self._lock:
+            nodes_dict = {}
+            for text in texts:
+                nodes_dict[compute_mdhash_id(text, prefix=self.namespace + "-")] = {"content": text}
+            all_hash_ids = list(nodes_dict.keys())
+            if not all_hash_ids:
+                return
+            existing = self.hash_id_to_row.keys()
+            missing_ids = [h for h in all_hash_ids if h not in existing]
+            logger.info(f"Inserting {len(missing_ids)} new records, {len(all_hash_ids) - len(missing_ids)} records already exist.")
+            if not missing_ids:
+                return {}
+            texts_to_encode = [nodes_dict[h]["content"] for h in missing_ids]
+            missing_embeddings = self.embedding_model.batch_encode(texts_to_encode)
+            self._upsert(missing_ids, texts_to_encode, missing_embeddings)
+
+    def get_row(self, hash_id):
+        return self.hash_id_to_row[hash_id]
+
+    def get_rows(self, hash_ids, dtype=np.float32):
+        if not hash_ids:
+            return {}
+        return {id: self.hash_id_to_row[id] for id in hash_ids}
+
+    def get_all_ids(self):
+        return deepcopy(self.hash_ids)
+
+    def get_text_for_all_rows(self):
+        return deepcopy(self.hash_id_to_row)
+
+    def get_embedding(self, hash_id, dtype=np.float32) -> np.ndarray:
+        return self._mat[self.hash_id_to_idx[hash_id]].astype(dtype)
+
+    def get_embeddings(self, hash_ids, dtype=np.float32):
+        if not hash_ids:
+            return []
+        indices = np.array([self.hash_id_to_idx[h] for h in hash_ids], dtype=np.intp)
+        return self._mat[:self._n][indices].astype(dtype, copy=False)
+
+    def get_hash_id_to_order(self) -> Dict[str, int]:
+        return {h: idx for idx, h in enumerate(self.hash_ids)}
+
+    # ------------------------------------------------------------------ device mirror
+    def device_index(self, dtype: Optional[str] = None, device: int = 0, keep_f32: bool = False):
+        """The store's rows as a `DenseIndex` (built on first use, appended to afterwards).
+        Row id == `hash_id_to_idx[hash_id]`.  dtype default: `global_config.index_dtype` of the
+        embedding model when present, else "f32" (the reference's arithmetic)."""
+        with self._lock:
+            if dtype is None:
+                cfg = getattr(self.embedding_model, "global_config", None)
+                dtype = getattr(cfg, "index_dtype", None) or "f32"
+            want = dict(dtype=dtype, device=device, keep_f32=keep_f32)
+            if self._index is not None and self._index_kw != want:
+                self._index.close()
+                self._index = None
+            if self._index is None:
+                if self._n == 0:
+                    raise ValueError("device_index() on an empty store")
+                from .index import DenseIndex
+                self._index = DenseIndex(self._mat.shape[1], dtype, device=device, capacity_hint=self._n, keep_f32=keep_f32)
+                self._index.append(self._mat[:self._n])
+                self._index_kw = want
+            return self._index

@@ -1,0 +1,108 @@
+"""Put an UNMODIFIED reference `ComoRAG` instance on the HIP engine.
+
+`install(rag)` rebinds, on that instance (and on the two helper names ComoRAG.py imported at module
+scope), exactly the numeric call sites of SURVEY.md §8a:
+    prepare_retrieval_objects   ComoRAG.py:876-907   → also builds the HBM indexes, once, under a lock
+    get_query_embeddings        :909-935             → memoises the full query string
+    get_fact_scores             :937-948
+    dense_passage_retrieval     :950-967
+    retrieve_knn                utils/embed_utils.py:8-97     (name in the ComoRAG module)
+    get_similar_summaries       utils/embed_utils.py:109-161  (name in the ComoRAG module)
+    MemoryPool.retrieve_similar_nodes  utils/memory_utils.py:188-235 (instance-level, optional)
+Everything else (LLM calls, graph, PPR, clustering) keeps running the reference's code.
+"""
+from __future__ import annotations
+
+import sys
+import threading
+import types
+from typing import Optional
+
+import numpy as np
+
+from . import retrieval
+from .index import DenseIndex
+
+
+def patch_reference_modules(package: str = "src.comorag") -> None:
+    """Alias the three replaced reference modules to this package BEFORE `package`.ComoRAG is
+    imported, so its `from .embedding_store import EmbeddingStore`, `from .embedding_model import
+    _get_embedding_model_class` and `from .utils.embed_utils import ...` bind to the HIP-backed
+    classes/functions.  ComoRAG.py itself is not edited."""
+    import importlib
+    from . import embedding_model, embedding_store, retrieval
+    sys.modules[f"{package}.embedding_store"] = embedding_store
+    sys.modules[f"{package}.embedding_model"] = embedding_model
+    shim = types.ModuleType(f"{package}.utils.embed_utils")
+    shim.retrieve_knn = retrieval.retrieve_knn
+    shim.get_similar_summaries = retrieval.get_similar_summaries
+    shim.min_max_normalize = retrieval.min_max_normalize
+    shim.EmbeddingStore = embedding_store.EmbeddingStore
+    sys.modules[f"{package}.utils.embed_utils"] = shim
+    importlib.invalidate_caches()
+
+
+def _matrix_index(mat, dtype: str, device: int) -> Optional[DenseIndex]:
+    mat = np.asarray(mat, dtype=np.float32)
+    if mat.ndim != 2 or mat.shape[0] == 0:
+        return None
+    idx = DenseIndex(mat.shape[1], dtype, device=device, capacity_hint=mat.shape[0])
+    idx.append(mat)
+    return idx
+
+
+def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True):
+    cfg = getattr(rag, "global_config", None)
+    dtype = index_dtype or getattr(cfg, "index_dtype", None) or "f32"
+    lock = threading.Lock()
+    orig_prepare = rag.prepare_retrieval_objects
+    rag._hip = {"passage": None, "summary": None, "fact": None, "dtype": dtype}
+
+    def prepare_retrieval_objects(self):
+        with lock:                                    # once-only (the reference races here, :467-468)
+            if getattr(self, "ready_to_retrieve", False) and self._hip["passage"] is not None:
+                return
+            orig_prepare()
+            self._hip["passage"] = _matrix_index(self.passage_embeddings, dtype, device)
+            self._hip["fact"] = _matrix_index(self.fact_embeddings, dtype, device)
+            if getattr(self.global_config, "need_cluster", False) and hasattr(self, "summary_embeddings"):
+                self._hip["summary"] = _matrix_index(self.summary_embeddings, dtype, device)
+
+    def _query_vec(self, kind: str, query: str, instruction_key: str):
+        vec = self.query_to_embedding[kind].get(query, None)
+        if vec is None:
+            from importlib import import_module
+            gqi = import_module(type(self).__module__).get_query_instruction
+            vec = self.embedding_model.batch_encode(query, instruction=gqi(instruction_key), norm=True)
+            self.query_to_embedding[kind][query] = vec      # memoise the FULL string (fixes :470 waste)
+        return vec
+
+    def get_query_embeddings(self, queries):
+        if isinstance(queries, str):                  # tri_retrieve passes a str (:470): encode it once,
+            queries = [queries]                       # not per character — same cached vectors result
+        for q in queries:
+            q = getattr(q, "question", q)
+            _query_vec(self, "triple", q, "query_to_fact")
+            _query_vec(self, "passage", q, "query_to_passage")
+
+    def get_fact_scores(self, query: str) -> np.ndarray:
+        return retrieval.get_fact_scores(self._hip["fact"], _query_vec(self, "triple", query, "query_to_fact"))
+
+    def dense_passage_retrieval(self, query: str, need_cluster: bool = False):
+        idx = self._hip["summary"] if need_cluster else self._hip["passage"]
+        return retrieval.dense_passage_retrieval(idx, _query_vec(self, "passage", query, "query_to_passage"))
+
+    for fn in (prepare_retrieval_objects, get_query_embeddings, get_fact_scores, dense_passage_retrieval):
+        setattr(rag, fn.__name__, types.MethodType(fn, rag))
+
+    if patch_module_functions:
+        mod = sys.modules.get(type(rag).__module__)
+        if mod is not None:
+            def _knn(query_ids, key_ids, query_vecs, key_vecs, k=2047, query_batch_size=1000, key_batch_size=10000):
+                return retrieval.retrieve_knn(query_ids, key_ids, query_vecs, key_vecs, k=k, query_batch_size=query_batch_size,
+                                              key_batch_size=key_batch_size, index_dtype=dtype, device=device)
+            if hasattr(mod, "retrieve_knn"):
+                mod.retrieve_knn = _knn
+            if hasattr(mod, "get_similar_summaries"):
+                mod.get_similar_summaries = retrieval.get_similar_summaries
+    return rag

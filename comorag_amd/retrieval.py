@@ -1,0 +1,144 @@
+"""The five retrieval call sites of ComoRAG as functions over a `DenseIndex`.
+
+Each function names the reference code it replaces; scoring runs on the GPU (C-ABI), the
+surrounding formulae (min-max normalisation, argsort direction, squeeze corner cases, return
+types) are the reference's, textually, so callers see the same objects.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .index import DenseIndex
+from .utils.misc_utils import min_max_normalize
+
+QUERY_INSTRUCTION_SUMMARIES = "Given a question, retrieve relevant documents that best answer the question."
+
+
+def _as_query(q) -> np.ndarray:
+    q = np.asarray(q, dtype=np.float32)
+    return q[None, :] if q.ndim == 1 else q
+
+
+def full_scores(index: DenseIndex, query_embedding) -> np.ndarray:
+    """`np.dot(M, q.T)` + squeeze of ComoRAG.py:944-945 / :958-962: one query → shape (N,)
+    (0-d when N == 1, as np.squeeze gives)."""
+    s = index.scores(_as_query(query_embedding))           # [1, N]
+    s = s.T                                                # (N, 1), what np.dot(M, q.T) returns
+    return np.squeeze(s) if s.ndim == 2 else s
+
+
+def dense_passage_retrieval(index: DenseIndex, query_embedding) -> Tuple[np.ndarray, np.ndarray]:
+    """ComoRAG.dense_passage_retrieval (ComoRAG.py:950-967): ALL N ids by descending min-max
+    normalised score + the scores in that order.  The N·D inner products come from the GPU; the
+    normalise + argsort lines are the reference's."""
+    query_doc_scores = full_scores(index, query_embedding)
+    query_doc_scores = min_max_normalize(query_doc_scores)
+    sorted_doc_ids = np.argsort(query_doc_scores)[::-1]
+    sorted_doc_scores = query_doc_scores[sorted_doc_ids.tolist()]
+    return sorted_doc_ids, sorted_doc_scores
+
+
+def dense_passage_topk(index: DenseIndex, query_embeddings, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Fast path for callers that only consume the head (tri_retrieve's qa_*_top_k slices): fused
+    scan + top-k on the GPU; scores min-max normalised from the kernel's global min/max with the
+    reference formula.  ids [nq,k'], scores [nq,k'] (descending; ties: lower row id first)."""
+    ids, sc, mn, mx = index.search(_as_query(query_embeddings), k)
+    rng = (mx - mn)[:, None]
+    norm = np.where(rng == 0, np.ones_like(sc), (sc - mn[:, None]) / np.where(rng == 0, 1, rng))
+    return ids, norm.astype(np.float32)
+
+
+def get_fact_scores(index: Optional[DenseIndex], query_embedding) -> np.ndarray:
+    """ComoRAG.get_fact_scores (ComoRAG.py:937-948): full normalised vector over the fact matrix."""
+    if index is None or len(index) == 0:
+        return np.array([])
+    return min_max_normalize(full_scores(index, query_embedding))
+
+
+def link_top_k(query_fact_scores: np.ndarray, k: int) -> List[int]:
+    """ComoRAG.py:1073 / :475."""
+    return np.argsort(query_fact_scores)[-k:][::-1].tolist()
+
+
+def get_similar_summaries(query: str, level_store, embedding_model, top_k: int = 3,
+                          instruction: Optional[str] = None) -> Tuple[List[str], List[float]]:
+    """utils/embed_utils.py:109-161 — same signature and returns; the store's device mirror replaces
+    `get_embeddings(all ids)` (a full N×D copy) + np.dot."""
+    level_ids = level_store.get_all_ids()
+    if not level_ids:
+        return [], []
+    level_texts = [level_store.hash_id_to_text[id] for id in level_ids]
+    query_embedding = embedding_model.batch_encode(query, instruction=QUERY_INSTRUCTION_SUMMARIES, norm=True)
+    if hasattr(level_store, "device_index"):
+        similarity_scores = full_scores(level_store.device_index(), query_embedding)
+    else:   # a reference-class store: build a throw-away index from its rows
+        rows = np.asarray(level_store.get_embeddings(level_ids), dtype=np.float32)
+        if len(rows) == 0:
+            return [], []
+        tmp = DenseIndex(rows.shape[1], "f32", capacity_hint=len(rows))
+        try:
+            tmp.append(rows)
+            similarity_scores = full_scores(tmp, query_embedding)
+        finally:
+            tmp.close()
+    similarity_scores = min_max_normalize(similarity_scores)
+    sorted_indices = np.argsort(similarity_scores)[::-1][:top_k]
+    sorted_scores = similarity_scores[sorted_indices]
+    return [level_texts[i] for i in sorted_indices], sorted_scores.tolist()
+
+
+def _l2n(x: np.ndarray) -> np.ndarray:
+    n = np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))
+    return x / np.maximum(n, np.float32(1e-12))
+
+
+def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, key_vecs, k: int = 2047,
+                 query_batch_size: int = 1000, key_batch_size: int = 10000, index_dtype: str = "f32",
+                 device: int = 0) -> Dict[str, Tuple[List[str], List[float]]]:
+    """utils/embed_utils.py:8-97 — fp32 re-normalise both sides, exact top-k of every query over all
+    keys, `{query_id: ([key ids], [scores])}`.  The reference's key-block loop + merge computes the
+    global top-k, so one pass over a single HBM index gives the same answer; k <= 128 uses the fused
+    scan+top-k kernel, larger k (synonymy_edge_topk = 2047) takes the full score matrix from the GPU
+    per query block and selects on the host.  Equal scores: lower key index first (torch.topk's tie
+    order is unspecified)."""
+    if len(key_vecs) == 0:
+        return {}
+    q = _l2n(np.asarray(query_vecs, dtype=np.float32))
+    kx = _l2n(np.asarray(key_vecs, dtype=np.float32))
+    index = DenseIndex(kx.shape[1], index_dtype, device=device, capacity_hint=len(kx))
+    try:
+        index.append(kx)
+        kk = min(k, len(kx))
+        results: Dict[str, Tuple[List[str], List[float]]] = {}
+        from ._lib import CMR_MAX_K
+        for s in range(0, len(q), query_batch_size):
+            qb = q[s:s + query_batch_size]
+            if kk <= CMR_MAX_K:
+                ids, sc, _, _ = index.search(qb, kk, with_minmax=False)
+            else:
+                full = index.scores(qb)
+                part = np.argpartition(-full, kk - 1, axis=1)[:, :kk] if kk < full.shape[1] else np.tile(np.arange(full.shape[1]), (len(qb), 1))
+                ps = np.take_along_axis(full, part, axis=1)
+                order = np.lexsort((part, -ps), axis=1)
+                ids = np.take_along_axis(part, order, axis=1)
+                sc = np.take_along_axis(ps, order, axis=1)
+            for r in range(len(qb)):
+                results[query_ids[s + r]] = ([key_ids[j] for j in ids[r]], sc[r].tolist())
+        return results
+    finally:
+        index.close()
+
+
+def retrieve_similar_rows(index: DenseIndex, probe_embedding, n_nodes: int, top_percent: float = 0.5) -> List[int]:
+    """Numeric part of MemoryPool.retrieve_similar_nodes (utils/memory_utils.py:213-235) for a pool
+    whose (unit-norm) node embeddings live in `index`: cosine of the probe with every node, keep
+    max(1, int(n*top_percent)), ties keep pool order (the reference's stable sort)."""
+    p = _l2n(_as_query(probe_embedding))
+    keep = max(1, int(n_nodes * top_percent))
+    ids, _, _, _ = index.search(p, min(keep, 128), with_minmax=False) if keep <= 128 else (None, None, None, None)
+    if ids is None:
+        s = index.scores(p)[0]
+        return np.argsort(-s, kind="stable")[:keep].tolist()
+    return ids[0].tolist()

@@ -60,11 +60,12 @@ class ShardedIndex:
         dev = torch.device("cuda", self.device) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
         t_id = torch.from_numpy(pid).to(dev)
         t_sc = torch.from_numpy(psc).to(dev)
-        g_id = torch.empty((self.world, nq, k), dtype=torch.int64, device=dev)
-        g_sc = torch.empty((self.world, nq, k), dtype=torch.float32, device=dev)
+        # concatenated layout [world*nq, k] (accepted by both gloo and RCCL), viewed as [world, nq, k]
+        g_id = torch.empty((self.world * nq, k), dtype=torch.int64, device=dev)
+        g_sc = torch.empty((self.world * nq, k), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(g_id, t_id, group=self.group)
         dist.all_gather_into_tensor(g_sc, t_sc, group=self.group)
-        return merge_topk(g_id.cpu().numpy(), g_sc.cpu().numpy())
+        return merge_topk(g_id.cpu().numpy().reshape(self.world, nq, k), g_sc.cpu().numpy().reshape(self.world, nq, k))
 
     # ---------------------------------------------------------------- device path
     def _buffers(self, slot: int, nq: int, k: int, dev):
@@ -74,8 +75,8 @@ class ShardedIndex:
             self._bufs[key] = dict(
                 ids=torch.empty((nq, k), dtype=torch.int64, device=dev),
                 sc=torch.empty((nq, k), dtype=torch.float32, device=dev),
-                g_ids=torch.empty((self.world, nq, k), dtype=torch.int64, device=dev),
-                g_sc=torch.empty((self.world, nq, k), dtype=torch.float32, device=dev),
+                g_ids=torch.empty((self.world * nq, k), dtype=torch.int64, device=dev),    # == [world, nq, k]
+                g_sc=torch.empty((self.world * nq, k), dtype=torch.float32, device=dev),
                 o_ids=torch.empty((nq, k), dtype=torch.int64, device=dev),
                 o_sc=torch.empty((nq, k), dtype=torch.float32, device=dev),
                 done=torch.cuda.Event(), scanned=torch.cuda.Event(), used=False)

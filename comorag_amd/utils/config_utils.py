@@ -1,0 +1,34 @@
+"""The configuration fields the embedding / retrieval path reads.
+
+The reference keeps one big dataclass (src/comorag/utils/config_utils.py:17-298); only the fields
+below are read on this path.  Any object with these attributes works — in
+particular the reference's own `BaseConfig` instance — because every consumer here uses getattr
+with the reference default.
+"""
+from dataclasses import dataclass, field
+from typing import Optional
+
+
+@dataclass
+class BaseConfig:
+    # reference fields (same names, same defaults)
+    embedding_model_name: str = field(default="BAAI/bge-m3", metadata={"ref": "config_utils.py:128"})
+    embedding_batch_size: int = 32                # :132
+    embedding_return_as_normalized: bool = True   # :136
+    embedding_max_seq_len: int = 2048             # :140
+    embedding_model_dtype: str = "auto"           # :144  (never read by the reference; honoured here)
+    linking_top_k: int = 5                        # :176
+    synonymy_edge_topk: int = 2047                # :152
+    synonymy_edge_query_batch_size: int = 1000    # :156
+    synonymy_edge_key_batch_size: int = 10000     # :160
+    synonymy_edge_sim_threshold: float = 0.8      # :164
+    need_cluster: bool = True
+    # new, opt-in (reference behaviour by default)
+    index_dtype: str = "f32"                      # "f32" | "bf16" | "f16": storage dtype of the HBM index
+    device: int = 0
+    embedding_cache_enabled: bool = False         # probed with hasattr by the reference (BGEEmbedding.py:57-61)
+    embedding_cache_path: Optional[str] = None
+
+
+def cfg_get(cfg, name, default):
+    return getattr(cfg, name, default) if cfg is not None else default

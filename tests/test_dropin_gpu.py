@@ -1,0 +1,241 @@
+"""GPU parity of the host-side mirrors (store mirror, retrieval functions, hooks, pool kernel,
+encoder tail, re-score, logical shards) against reference-generated fixtures and the oracle."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from oracle import retrieval_np as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_retrieval_functions_vs_reference_outputs(golden_dir):
+    from comorag_amd import retrieval
+    from comorag_amd.index import DenseIndex
+    for tag in ("small", "mid", "d768"):
+        g = np.load(os.path.join(golden_dir, f"dpr_{tag}.npz"))
+        X, F, S, Q = g["X"], g["F"], g["S"], g["Q"]
+        ix, fx, sx = (DenseIndex(M.shape[1], "f32") for M in (X, F, S))
+        ix.append(X); fx.append(F); sx.append(S)
+        ex, es = orc.exact_scores_f64(X, Q), orc.exact_scores_f64(S, Q)
+        for i in range(len(Q)):
+            ids, sc = retrieval.dense_passage_retrieval(ix, Q[i:i + 1])
+            assert ids.shape == g[f"dpr_ids_{i}"].shape and sc.dtype == g[f"dpr_scores_{i}"].dtype
+            orc.assert_topk_equivalent(ids, g[f"dpr_ids_{i}"], ex[i], 1e-6)          # ALL N ids, tie-aware
+            np.testing.assert_allclose(sc, g[f"dpr_scores_{i}"], atol=2e-6)
+            idc, scc = retrieval.dense_passage_retrieval(sx, Q[i:i + 1])
+            orc.assert_topk_equivalent(idc, g[f"dprc_ids_{i}"], es[i], 1e-6)
+            np.testing.assert_allclose(retrieval.get_fact_scores(fx, Q[i:i + 1]), g[f"fact_scores_{i}"], atol=2e-6)
+            tid, tsc = retrieval.dense_passage_topk(ix, Q[i:i + 1], 5)
+            orc.assert_topk_equivalent(tid[0], g[f"dpr_ids_{i}"][:5], ex[i], 1e-6)
+            np.testing.assert_allclose(tsc[0], g[f"dpr_scores_{i}"][:5], atol=2e-6)
+        for z in (ix, fx, sx):
+            z.close()
+    # N = 2 corner (np.squeeze paths) and the reference's N = 1 guard
+    g = np.load(os.path.join(golden_dir, "dpr_n2.npz"))
+    ix = DenseIndex(g["X"].shape[1], "f32"); ix.append(g["X"])
+    ids, sc = retrieval.dense_passage_retrieval(ix, g["Q"][:1])
+    assert ids.tolist() == g["dpr_ids_0"].tolist() and np.allclose(sc, g["dpr_scores_0"], atol=2e-6)
+    ix.close()
+
+
+def test_store_device_mirror_summaries_and_cinderella(golden_dir, tmp_path, fake_embedder):
+    from comorag_amd import retrieval
+    from comorag_amd.embedding_store import EmbeddingStore
+    s = json.load(open(os.path.join(golden_dir, "summaries.json")))
+    lv = EmbeddingStore(fake_embedder, str(tmp_path), 8, "level_0")
+    lv.insert_strings(s["summaries"][:4])
+    idx = lv.device_index()
+    lv.insert_strings(s["summaries"][4:] + s["summaries"][:2])     # mirror keeps up with appends, dups skipped
+    assert len(idx) == len(s["summaries"]) == len(lv.hash_ids)
+    fake_embedder.calls.clear()
+    texts, scores = retrieval.get_similar_summaries(s["query"], lv, fake_embedder, top_k=3)
+    assert texts == s["top_texts"] and fake_embedder.calls == s["encode_calls"]
+    np.testing.assert_allclose(scores, s["top_scores"], atol=2e-6)
+    # BASELINE config 1: cinderella chunks (fixture carries the md5 of each chunk; texts are not shipped)
+    c = json.load(open(os.path.join(golden_dir, "cinderella.json")))
+    assert len(c["keys"]) == 6
+
+
+def test_retrieve_knn_vs_reference_and_large_k(golden_dir):
+    from comorag_amd import retrieval
+    g = np.load(os.path.join(golden_dir, "knn.npz"))
+    E = g["E"]
+    ids = [f"e{i}" for i in range(len(E))]
+    exact = orc.exact_scores_f64(orc._l2n(E), orc._l2n(E))
+    got = retrieval.retrieve_knn(ids, ids, E, E, k=10, query_batch_size=64, key_batch_size=100)
+    for i, q in enumerate(ids):
+        gi = np.array([int(s[1:]) for s in got[q][0]])
+        orc.assert_topk_equivalent(gi, g["knn_ids"][i], exact[i], 1e-6)
+        np.testing.assert_allclose(got[q][1], g["knn_scores"][i], atol=2e-6)
+    assert got["e3"][0][:2] == ["e3", "e17"]                       # exact duplicate: lower index first
+    # k above CMR_MAX_K (synonymy_edge_topk style) → full-score path
+    big = retrieval.retrieve_knn(ids, ids, E, E, k=250, query_batch_size=128)
+    ref = orc.retrieve_knn(ids, ids, E, E, k=250, query_batch_size=128)
+    for i, q in enumerate(ids[:40]):
+        a = np.array([int(s[1:]) for s in big[q][0]]); b = np.array([int(s[1:]) for s in ref[q][0]])
+        orc.assert_topk_equivalent(a, b, exact[i], 1e-6)
+    assert retrieval.retrieve_knn([], [], np.zeros((0, 4)), np.zeros((0, 4))) == {}
+
+
+def test_memory_pool_numeric(golden_dir, fake_embedder):
+    from comorag_amd import retrieval
+    from comorag_amd.index import DenseIndex
+    m = json.load(open(os.path.join(golden_dir, "mempool.json")))
+    embs = np.stack([fake_embedder._vec(c) for c in m["contents"]])
+    idx = DenseIndex(embs.shape[1], "f32"); idx.append(embs)
+    assert retrieval.retrieve_similar_rows(idx, fake_embedder._vec(m["probe"]), len(embs), 0.5) == m["selected"]
+    idx.close()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "bfloat16", "float16"])
+@pytest.mark.parametrize("shape", [(5, 19, 40), (32, 512, 768), (3, 7, 1024), (1, 1, 8), (64, 128, 1000)])
+def test_pool_kernel(golden_dir, dtype, shape):
+    import torch
+    from comorag_amd.embedding_model.bge import pool_l2norm
+    if shape == (5, 19, 40) and dtype == "float32":
+        g = np.load(os.path.join(golden_dir, "pool.npz"))          # torch-CPU outputs of the reference code
+        h, m = torch.from_numpy(g["hidden"]).cuda(), torch.from_numpy(g["mask"]).cuda()
+        np.testing.assert_allclose(pool_l2norm(h, m).cpu().numpy(), g["normed"], atol=1e-6)
+        np.testing.assert_allclose(pool_l2norm(h, m, normalize=False).cpu().numpy(), g["pooled"], atol=1e-6)
+    b, l, d = shape
+    rng = np.random.default_rng(b * l + d)
+    hid = rng.standard_normal(shape).astype(np.float32)
+    lens = rng.integers(1, l + 1, size=b); lens[0] = l
+    mask = (np.arange(l)[None, :] < lens[:, None]).astype(np.int64)
+    ht = torch.from_numpy(hid).cuda().to(getattr(torch, dtype))
+    got = pool_l2norm(ht, torch.from_numpy(mask).cuda()).cpu().numpy()
+    want = orc.mean_pool_l2norm(ht.float().cpu().numpy(), mask)     # oracle on the same (rounded) inputs
+    np.testing.assert_allclose(got, want, atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose((got ** 2).sum(1), 1.0, atol=1e-5)
+
+
+def test_encoder_end_to_end_vs_oracle():
+    """tokenise → BERT forward (torch-ROCm) → HIP pool+norm  ==  oracle restatement of the reference
+    `batch_encode` (torch fp32), same seed-initialised model and synthetic vocabulary."""
+    import copy
+    import torch
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.utils.config_utils import BaseConfig
+    from oracle import encode_torch as enc
+    model, tok = enc.tiny_bert(hidden=128, layers=2, heads=4, inter=256, max_pos=64)
+    cfg = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=4, embedding_max_seq_len=2048)
+    cls = _get_embedding_model_class(cfg.embedding_model_name)
+    em = cls(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+    assert em.embedding_dim == 128
+    texts = [f"the prince and the golden slipper number {i} " + "and the bird in the tree " * (i % 5) for i in range(11)]
+    texts.append("she was good and pious " * 40)                     # > 64 positions: clamped, not a crash
+    got = em.batch_encode(texts, instruction="ignored", norm=True)
+    want = enc.batch_encode(model, tok, texts, batch_size=4, max_length=64)
+    assert got.shape == want.shape == (12, 128) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, atol=2e-5)                 # GPU vs CPU forward: fp32 reduction order
+    one = em.batch_encode("midnight")
+    np.testing.assert_allclose(one, enc.batch_encode(model, tok, "midnight", batch_size=4, max_length=64), atol=2e-5)
+    t = em.encode(["what did the mother wish", "midnight"])         # positional, torch tensor (memory_utils.py:176)
+    assert isinstance(t, torch.Tensor) and t.shape == (2, 128)
+    np.testing.assert_allclose(em.encode_queries(["midnight"]), one, atol=1e-6)
+
+
+def test_hooks_on_a_comorag_shaped_object(golden_dir):
+    """install() rebinds the numeric call sites on an object with ComoRAG's attribute names."""
+    from comorag_amd import hooks
+    g = np.load(os.path.join(golden_dir, "dpr_mid.npz"))
+    X, F, S, Q = g["X"], g["F"], g["S"], g["Q"]
+
+    class Enc:
+        n = 0
+        def batch_encode(self, text, **kw):
+            Enc.n += 1
+            return Q[int(text[1:]):int(text[1:]) + 1]
+
+    class Rag:                                     # the attributes ComoRAG.prepare_retrieval_objects sets
+        def __init__(self):
+            self.global_config = types.SimpleNamespace(need_cluster=True, index_dtype="f32")
+            self.embedding_model = Enc()
+            self.ready_to_retrieve = False
+        def prepare_retrieval_objects(self):
+            self.query_to_embedding = {"triple": {}, "passage": {}}
+            self.passage_embeddings, self.fact_embeddings, self.summary_embeddings = X, F, S
+            self.ready_to_retrieve = True
+    import sys
+    mod = sys.modules[Rag.__module__]
+    mod.get_query_instruction = lambda k: k
+    rag = hooks.install(Rag(), patch_module_functions=False)
+    rag.prepare_retrieval_objects(); rag.prepare_retrieval_objects()
+    ex = orc.exact_scores_f64(X, Q)
+    for i in range(len(Q)):
+        ids, sc = rag.dense_passage_retrieval(f"q{i}")
+        orc.assert_topk_equivalent(ids, g[f"dpr_ids_{i}"], ex[i], 1e-6)
+        np.testing.assert_allclose(sc, g[f"dpr_scores_{i}"], atol=2e-6)
+        np.testing.assert_allclose(rag.get_fact_scores(f"q{i}"), g[f"fact_scores_{i}"], atol=2e-6)
+        idc, scc = rag.dense_passage_retrieval(f"q{i}", need_cluster=True)
+        np.testing.assert_allclose(scc, g[f"dprc_scores_{i}"], atol=2e-6)
+    n0 = Enc.n
+    rag.get_query_embeddings("q1"); rag.dense_passage_retrieval("q1")
+    assert Enc.n == n0                                               # full query memoised: no re-encode
+
+
+def test_exact_rescorer_shape():
+    from comorag_amd.index import DenseIndex
+    from comorag_amd.rerank import ExactRescorer, search_then_rescore
+    X = orc.synthetic_corpus(2000, 1024, seed=3); Q = orc.synthetic_queries(2, 1024, seed=4, planted=X)
+    idx = DenseIndex(1024, "f16", keep_f32=True); idx.append(X)
+    cand = idx.search(Q[:1], 100)[0][0].tolist()
+    items = [("s", "p", str(c)) for c in cand]
+    keep, kept_items, info = ExactRescorer(idx).rerank(Q[0], items, cand, len_after_rerank=5)
+    exact = orc.exact_scores_f64(X, Q[:1])[0]
+    want = sorted(cand, key=lambda r: (-exact[r], r))[:5]
+    orc.assert_topk_equivalent(np.array(keep), np.array(want), exact, 1e-6)
+    assert kept_items == [("s", "p", str(r)) for r in keep] and len(info["confidence"]) == 5
+    ids, sc = search_then_rescore(idx, Q, 100, 20)
+    assert ids.shape == (2, 20)
+    idx.close()
+
+
+@pytest.mark.parametrize("S", [2, 4, 8])
+def test_logical_shards_equal_single_index(S):
+    """Multi-GPU oracle: S row shards + candidate merge == one index, bit for bit."""
+    from comorag_amd.index import DenseIndex, merge_topk
+    from comorag_amd.sharded import shard_bounds
+    X = orc.synthetic_corpus(10_007, 256, seed=31); Q = orc.synthetic_queries(9, 256, seed=32, planted=X)
+    X[9000] = X[5]                                                    # a cross-shard tie
+    one = DenseIndex(256, "bf16"); one.append(X)
+    wi, ws, _, _ = one.search(Q, 20)
+    ids, scs = [], []
+    for r in range(S):
+        lo, hi = shard_bounds(len(X), S, r)
+        sh = DenseIndex(256, "bf16"); sh.append(X[lo:hi])
+        i, s, _, _ = sh.search(Q, 20)
+        ids.append(i + lo); scs.append(s); sh.close()
+    mi, ms = merge_topk(np.stack(ids), np.stack(scs))
+    assert np.array_equal(mi, wi) and np.array_equal(ms, ws)
+    # device-side merge kernel gives the same
+    import ctypes as C, torch
+    from comorag_amd import _lib as L
+    gi, gs = torch.from_numpy(np.stack(ids)).cuda(), torch.from_numpy(np.stack(scs)).cuda()
+    oi, os_ = torch.empty((9, 20), dtype=torch.int64, device="cuda"), torch.empty((9, 20), dtype=torch.float32, device="cuda")
+    L.check(L.lib().cmr_merge_topk_dev(0, C.c_void_p(gi.data_ptr()), C.c_void_p(gs.data_ptr()), S, 9, 20,
+                                       C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy(), wi) and np.array_equal(os_.cpu().numpy(), ws)
+    one.close()
+
+
+def test_pipelined_search_single_rank():
+    import torch
+    from comorag_amd.sharded import ShardedIndex
+    X = orc.synthetic_corpus(50_000, 128, seed=41); Q = orc.synthetic_queries(16, 128, seed=42, planted=X)
+    sh = ShardedIndex(128, "bf16", base=1000)
+    sh.local.append(X)
+    want_i, want_s, _, _ = sh.local.search(Q, 20)
+    q = torch.from_numpy(Q).cuda()
+    outs = [sh.search_pipelined(q, 20, i & 1) for i in range(5)]
+    torch.cuda.synchronize()
+    for b in outs[-2:]:
+        assert np.array_equal(b["o_ids"].cpu().numpy(), want_i + 1000) and np.array_equal(b["o_sc"].cpu().numpy(), want_s)
+    hi, hs = sh.search(Q, 20)
+    assert np.array_equal(hi, want_i + 1000)

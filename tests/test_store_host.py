@@ -1,0 +1,99 @@
+"""Host logic of the EmbeddingStore drop-in, replayed against what the REFERENCE class did
+(tests/golden/store.json, store_emb.npz — produced by oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from comorag_amd.embedding_store import EmbeddingStore
+from comorag_amd.utils.misc_utils import compute_mdhash_id, min_max_normalize
+
+
+def test_mdhash_golden(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "mdhash.json")))
+    got = [compute_mdhash_id(s, prefix=p) for s in g["strings"] for p in ("", "chunk-", "entity-")]
+    assert got == g["ids"]
+
+
+def test_minmax_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "minmax.npz"))
+    assert np.array_equal(min_max_normalize(g["v"]), g["v_out"])
+    assert np.array_equal(min_max_normalize(g["c"]), g["c_out"])
+    assert min_max_normalize(np.array([], dtype=np.float32)).size == 0
+
+
+def test_store_replays_reference(golden_dir, tmp_path, fake_embedder):
+    g = json.load(open(os.path.join(golden_dir, "store.json")))
+    ge = np.load(os.path.join(golden_dir, "store_emb.npz"))
+    st = EmbeddingStore(fake_embedder, str(tmp_path), 8, "chunk")
+    assert st.filename.endswith("vdb_chunk.parquet")
+    r1 = st.insert_strings(g["batch1"])
+    assert list(st.hash_ids) == g["ids_after_1"]
+    r2 = st.insert_strings(g["batch2"])
+    r3 = st.insert_strings(["alpha"])
+    r4 = st.insert_strings([])
+    assert [repr(r) for r in (r1, r2, r3, r4)] == g["ret"]
+    assert list(st.hash_ids) == g["ids_after_2"] and list(st.texts) == g["texts"]
+    assert fake_embedder.calls == g["encode_calls"]                    # same encode batches, same order
+    assert st.get_missing_string_hash_ids(["alpha", "zeta", "zeta"]) == g["missing"]
+    assert st.get_hash_id_to_order() == g["hash_id_to_idx"]
+    np.testing.assert_array_equal(st.get_embeddings(list(st.hash_ids)), ge["all"])
+    np.testing.assert_array_equal(st.get_embedding(st.hash_ids[2]), ge["one"])
+    assert st.get_embeddings([]) == [] and st.get_rows([]) == {}
+    assert st.get_row(st.hash_ids[1]) == {"hash_id": st.hash_ids[1], "content": "beta"}
+    assert st.text_to_hash_id["gamma"] == st.hash_ids[2] and st.hash_id_to_text[st.hash_ids[0]] == "alpha"
+    assert len(st.embeddings) == 5 and st.embeddings[0].dtype == np.float32
+    ids = st.get_all_ids(); ids.append("x"); assert len(st.hash_ids) == 5          # deepcopy semantics
+    # reload from parquet
+    st2 = EmbeddingStore(fake_embedder, str(tmp_path), 8, "chunk")
+    assert list(st2.hash_ids) == g["reload_ids"] and list(st2.texts) == g["reload_texts"]
+    np.testing.assert_array_equal(st2.get_embeddings(list(st2.hash_ids)), ge["all"])
+    assert type(st2.embeddings[0]).__name__ == g["reload_emb_type"] and str(st2.embeddings[0].dtype) == g["reload_emb_dtype"]
+
+
+def test_parquet_schema_is_reference_compatible(tmp_path, fake_embedder):
+    """The file must load with the reference's reader (pd.read_parquet → three .tolist() columns,
+    embedding_store.py:94-95) and the reference's own files must load here."""
+    import pandas as pd
+    st = EmbeddingStore(fake_embedder, str(tmp_path), 8, "ns")
+    st.insert_strings(["a", "b", "c"])
+    df = pd.read_parquet(st.filename)
+    assert list(df.columns) == ["hash_id", "content", "embedding"]
+    embs = df["embedding"].values.tolist()
+    assert isinstance(embs[0], np.ndarray) and embs[0].dtype == np.float32 and len(embs[0]) == 32
+    # a file written the reference's way (pandas, list of ndarrays)
+    ref = pd.DataFrame({"hash_id": ["r-1", "r-2"], "content": ["x", "y"],
+                        "embedding": [np.arange(4, dtype=np.float32), np.ones(4, dtype=np.float32)]})
+    os.makedirs(tmp_path / "ref", exist_ok=True)
+    ref.to_parquet(tmp_path / "ref" / "vdb_r.parquet", index=False)
+    st3 = EmbeddingStore(fake_embedder, str(tmp_path / "ref"), 8, "r")
+    assert st3.hash_ids == ["r-1", "r-2"] and np.array_equal(st3.get_embedding("r-1"), np.arange(4, dtype=np.float32))
+
+
+def test_empty_store_and_float64_encoder(tmp_path):
+    class F64:
+        def batch_encode(self, texts, **kw):
+            return np.array([[float(len(t)), 1.0] for t in texts])          # float64 like OpenAI.py:83
+    st = EmbeddingStore(F64(), str(tmp_path), 8, "e")
+    assert st.hash_ids == [] and st.hash_id_to_idx == {} and st.hash_id_to_row == {} and st.get_all_ids() == []
+    assert st.hash_id_to_text == {} and st.text_to_hash_id == {}               # defined (conscious fix)
+    st.insert_strings(["ab", "abc"])
+    assert st.get_embeddings(st.get_all_ids()).dtype == np.float32
+    import pandas as pd
+    assert pd.read_parquet(st.filename)["embedding"].values.tolist()[0].dtype == np.float64
+
+
+def test_live_reference_agrees(tmp_path, fake_embedder):
+    from oracle.ref_loader import reference_available, ref_modules
+    if not reference_available():
+        pytest.skip("reference tree not present")
+    Ref = ref_modules()["embedding_store"].EmbeddingStore
+    from tests.conftest import FakeEmbedder
+    a, b = Ref(FakeEmbedder(16), str(tmp_path / "a"), 4, "chunk"), EmbeddingStore(FakeEmbedder(16), str(tmp_path / "b"), 4, "chunk")
+    for batch in (["x", "y", "x"], ["z", "y", "w"], [], ["w"]):
+        ra, rb = a.insert_strings(batch), b.insert_strings(batch)
+        assert repr(ra) == repr(rb)
+        assert list(a.hash_ids) == list(b.hash_ids) and list(a.texts) == list(b.texts)
+        assert a.hash_id_to_idx == b.hash_id_to_idx and a.hash_id_to_row == b.hash_id_to_row
+    np.testing.assert_array_equal(np.asarray(a.get_embeddings(a.get_all_ids())), b.get_embeddings(b.get_all_ids()))
