@@ -60,12 +60,14 @@ def gen_rows_dev(torch, lo, hi, dim, device, block=250_000):
         yield x[s - b * block:e - b * block].contiguous()
 
 
-def build_shard(torch, args, rows, rank, world, device):
+def build_shard(torch, args, rows, rank, world, device, keep_host=None):
     from comorag_amd.sharded import ShardedIndex, shard_bounds
     lo, hi = shard_bounds(rows, world, rank)
     sh = ShardedIndex(args.dim, args.dtype, device=device.index, rank=rank, world=world, base=lo, capacity_hint=hi - lo)
     for blk in gen_rows_dev(torch, lo, hi, args.dim, device):
         sh.local.append_dev(blk)
+        if keep_host is not None:
+            keep_host.append(blk.cpu().numpy())
     torch.cuda.synchronize(device)
     return sh
 
@@ -94,32 +96,65 @@ def run_steps(torch, dist, sh, q, k, steps, warmup, world, device):
     return dt, prof
 
 
-def cpu_baseline(args, seconds):
+def cpu_baseline(args, seconds, X, Q, gpu_ids):
     """Oracle (numpy restatement of ComoRAG.dense_passage_retrieval, ComoRAG.py:950-967: np.dot +
-    min-max + full argsort, fp32, OpenBLAS threads = all cores) on a 1M-row slice of the workload."""
+    min-max + full argsort, fp32, OpenBLAS on all cores) on the first 1 M rows of the SAME corpus the
+    GPU scanned (copied back from HBM), plus recall@20 of the bf16 GPU result vs the fp32 CPU ranking."""
     from oracle import retrieval_np as orc
     try:
         from threadpoolctl import threadpool_info
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count() or 1
-    n = min(args.rows, 1_000_000)
-    X = np.concatenate([orc.synthetic_corpus(min(250_000, n - s), args.dim, seed=1234, block=s // 250_000)
-                        for s in range(0, n, 250_000)])
-    Q = orc.synthetic_queries(args.batch, args.dim, seed=4321)
+    n = len(X)
     orc.dense_passage_retrieval(X, Q[:1])  # warm
     t0 = time.perf_counter()
     done = 0
-    while time.perf_counter() - t0 < seconds and done < 4 * args.batch:
-        orc.dense_passage_retrieval(X, Q[done % args.batch:done % args.batch + 1])
+    while time.perf_counter() - t0 < seconds and done < 4 * len(Q):
+        orc.dense_passage_retrieval(X, Q[done % len(Q):done % len(Q) + 1])
         done += 1
     dt = time.perf_counter() - t0
     qps_sample = done / dt
     scale = n / args.rows
+    ref_ids, _ = orc.topk_rule(Q @ X.T, args.k)
+    recall = float(np.mean([len(set(gpu_ids[i].tolist()) & set(ref_ids[i].tolist())) / args.k for i in range(len(Q))]))
     return {"value": qps_sample * scale, "unit": "queries/s", "cores": int(blas_threads), "kind": "port",
-            "sample": f"{done} single-query dense_passage_retrieval calls (np.dot+min-max+argsort, fp32) over a "
-                      f"{n}-row slice in {dt:.1f}s = {qps_sample:.2f} q/s; linearly scaled x{scale:g} to {args.rows} rows",
-            "host_cpus": os.cpu_count()}
+            "sample": f"{done} single-query dense_passage_retrieval calls (np.dot+min-max+argsort, fp32) over the first "
+                      f"{n} rows of the bench corpus in {dt:.1f}s = {qps_sample:.2f} q/s; linearly scaled x{scale:g} to {args.rows} rows",
+            "host_cpus": os.cpu_count(), "recall_at_k_vs_cpu_fp32": recall,
+            "recall_note": f"top-{args.k} ids of the {args.dtype} HIP index vs fp32 numpy ranking, {len(Q)} queries, {n} rows"}
+
+
+def host_api_rate(torch, sh, Qh, k, steps=30):
+    """Same batch through the host-buffer API (H2D queries, D2H results, one sync per call)."""
+    for _ in range(3):
+        sh.local.search(Qh, k)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sh.local.search(Qh, k)
+    dt = time.perf_counter() - t0
+    return {"value": len(Qh) * steps / dt, "unit": "queries/s", "ms_per_call": dt / steps * 1e3}
+
+
+def encode_rate(torch, device, kind="base", n_chunks=256, dtype="auto"):
+    """Corpus-embed chunks/s: tokenise + encoder forward (PyTorch-ROCm, random-init BERT of BGE shape)
+    + HIP masked mean-pool/L2-norm, batch 32, ~480-token chunks truncated to 512 positions."""
+    from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
+    from comorag_amd.utils.config_utils import BaseConfig
+    from comorag_amd.utils.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer()
+    cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_batch_size=32, embedding_model_dtype=dtype,
+                     device=device.index or 0)
+    em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert(kind, vocab_size=len(tok)), tokenizer=tok)
+    chunks = synthetic_chunks(words, n_chunks)
+    em.batch_encode(chunks[:64])
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    out = em.batch_encode(chunks)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return {"value": n_chunks / dt, "unit": "chunks/s", "model": f"BERT-{kind} shape, random init, {dtype}", "batch": 32,
+            "chunks": n_chunks, "embedding_dim": int(out.shape[1])}
 
 
 def main():
@@ -165,21 +200,41 @@ def main():
                      "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"],
                      "rows_per_gpu": len(sh)},
     }
+    prof_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+    if os.path.exists(prof_file):
+        pj = json.load(open(prof_file))
+        w = pj.get("workload", {})
+        if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (len(sh), args.dim, args.dtype, args.batch, args.k):
+            out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r1_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)"
     sh.local.close()
     del sh
-    if rank == 0 and world == 1 and not args.no_extra and args.rows != 1_000_000:
-        # BASELINE config 2: 1 M x 768 bf16, B=64, k=20 on one GPU
-        sh2 = build_shard(torch, args, 1_000_000, 0, 1, device)
-        dt2, prof2 = run_steps(torch, dist, sh2, q, args.k, max(args.steps, 100), args.warmup, 1, device)
+    out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = {}
+        host_blocks = []
+        rows2 = min(args.rows, 1_000_000)
+        sh2 = build_shard(torch, args, rows2, 0, 1, device, keep_host=host_blocks)        # BASELINE config 2 when rows >= 1M
+        steps2 = max(args.steps, 100)
+        dt2, prof2 = run_steps(torch, dist, sh2, q, args.k, steps2, args.warmup, 1, device)
         ms2 = prof2["total_ms"] / max(prof2["launches"], 1)
-        out["extra"] = {"config2_1M_rows": {"value": args.batch * max(args.steps, 100) / dt2, "unit": "queries/s",
-                                            "ms_per_step": dt2 / max(args.steps, 100) * 1e3, "kernel_ms": ms2,
-                                            "hbm_GBps": prof2["bytes_per_launch"] / (ms2 * 1e-3) / 1e9 if ms2 else 0.0}}
+        extra[f"config2_{rows2}_rows"] = {"value": args.batch * steps2 / dt2, "unit": "queries/s", "ms_per_step": dt2 / steps2 * 1e3,
+                                          "kernel_ms": ms2, "hbm_GBps": prof2["bytes_per_launch"] / (ms2 * 1e-3) / 1e9 if ms2 else 0.0,
+                                          "frac_of_8TBps": prof2["bytes_per_launch"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS if ms2 else 0.0}
+        Qh = q.cpu().numpy()
+        extra["host_buffer_api"] = host_api_rate(torch, sh2, Qh, args.k)
+        extra["host_buffer_api"]["note"] = f"PCIe-inclusive: {rows2} rows, H2D queries + D2H results + sync per call"
+        gpu_ids = sh2.local.search(Qh, args.k)[0]
         sh2.local.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-    elif rank == 0:
-        out["cpu_baseline"] = None
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, np.concatenate(host_blocks), Qh, gpu_ids)
+        del host_blocks
+        try:
+            extra["corpus_embed"] = encode_rate(torch, device, "base", 256, "auto")
+            extra["corpus_embed_bf16"] = encode_rate(torch, device, "base", 256, "bf16")
+        except Exception as e:  # the headline line must still print
+            extra["corpus_embed"] = {"error": repr(e)[:300]}
+        out["extra"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -73,6 +73,16 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} not found. Build it with `python -m comorag_amd.build` "
                 "(hipcc --offload-arch=gfx950). comorag_amd has no CPU fallback.")
+        # One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (soname
+        # without the ".7"), so loading this library first would bring up /opt/rocm's runtime and
+        # torch's second runtime then finds no GPU.  When torch is installed, let it load its runtime
+        # (RTLD_GLOBAL) first: this library's HIP symbols then bind to that same runtime, and torch
+        # streams / tensors can be handed across the C-ABI.  Without torch the library uses the ROCm
+        # install it was linked against.
+        if not os.environ.get("COMORAG_HIP_NO_TORCH"):
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError = header/library drift: fail loudly

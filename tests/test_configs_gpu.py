@@ -1,0 +1,89 @@
+"""BASELINE configs 4 and 5 as parity cases (configs 1-3 are covered in test_oracle_pin.py,
+test_search_gpu.py::test_c2_size_properties and the logical-shard / gloo tests)."""
+import numpy as np
+import pytest
+
+from oracle import retrieval_np as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config4_probe_loop_with_incremental_append():
+    """5 reasoning cycles x 8 probing queries over a 2 M-chunk memory pool; after every cycle the
+    pool grows (25 rows = 3 nodes x 8 probes + 1 fusion, utils/memory_utils.py:176,297-300; and one
+    65,536-row burst that forces a capacity doubling via hipMemcpyAsync).  Checks: every search
+    equals a bulk-built index of the same rows bit for bit, new rows are retrievable immediately,
+    ids/scores agree with the oracle on the rounded inputs."""
+    import torch
+    from comorag_amd.index import DenseIndex
+    n0, d, k = 2_000_000, 768, 20
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    idx = DenseIndex(d, "bf16", capacity_hint=n0)           # exactly full: the first append must grow
+    host = []
+    for _ in range(8):
+        x = torch.randn((n0 // 8, d), generator=g, device="cuda"); x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+        idx.append_dev(x); host.append(x.cpu().numpy())
+    X = np.concatenate(host); del host
+    rng = np.random.default_rng(5)
+    cap0 = idx.device_bytes
+    for cycle in range(5):
+        probes = orc.synthetic_queries(8, d, seed=1000 + cycle, planted=X[rng.integers(0, len(X), 4)])
+        ids, sc, mn, mx = idx.search(probes, k)
+        Xr, Pr = orc.bf16_round(X), orc.bf16_round(probes)
+        s32 = Pr @ Xr.T
+        ref_ids, _ = orc.topk_rule(s32, k)
+        for i in range(8):
+            if not np.array_equal(ids[i], ref_ids[i]):
+                cols = np.union1d(ids[i], ref_ids[i])
+                ex = np.full(len(X), -np.inf); ex[cols] = Pr[i].astype(np.float64) @ Xr[cols].astype(np.float64).T
+                orc.assert_topk_equivalent(ids[i], ref_ids[i], ex, 4e-6)
+            np.testing.assert_allclose(sc[i], s32[i][ids[i]], atol=4e-6)
+        np.testing.assert_allclose(mx, s32.max(1), atol=4e-6)
+        n_new = 65_536 if cycle == 2 else 25
+        new = orc.synthetic_corpus(n_new, d, seed=2000 + cycle)
+        new[0] = probes[0]                                   # the "fused node" for probe 0
+        idx.append(new)
+        X = np.concatenate([X, new])
+        hit, hsc, _, _ = idx.search(probes[:1], 1)
+        assert hit[0, 0] == len(X) - n_new and hsc[0, 0] > 0.99    # retrievable immediately, right global row id
+    assert len(idx) == len(X) and idx.device_bytes > cap0           # grew (capacity doubling path)
+    bulk = DenseIndex(d, "bf16", capacity_hint=len(X)); bulk.append(X)
+    pq = orc.synthetic_queries(8, d, seed=77)
+    a, b = idx.search(pq, k), bulk.search(pq, k)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+    idx.close(); bulk.close()
+
+
+def test_config5_encode_then_search_then_rescore():
+    """BGE-large shape (1024-d) fp16: ~200 K tokens of narrative text (391 chunks x 512 tokens) →
+    encoder (random init: no weights offline) → fp16 index with fp32 shadow → top-100 → exact fp32
+    top-20.  Parity: pooled vectors are unit norm and equal the oracle pool on the same hidden
+    states (test_dropin_gpu.py); here the search + rescore stages are checked against the oracle on
+    the produced embeddings."""
+    import torch
+    from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
+    from comorag_amd.index import DenseIndex
+    from comorag_amd.utils.config_utils import BaseConfig
+    from comorag_amd.utils.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer(8000)
+    cfg = BaseConfig(embedding_model_name="bge-large-random-init", embedding_batch_size=32, embedding_model_dtype="fp16")
+    em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert("large", vocab_size=len(tok)), tokenizer=tok)
+    chunks = synthetic_chunks(words, 391, tokens_per_chunk=500)
+    E = em.batch_encode(chunks)
+    assert E.shape == (391, 1024) and E.dtype == np.float32
+    np.testing.assert_allclose((E.astype(np.float64) ** 2).sum(1), 1.0, atol=1e-5)
+    Q = em.batch_encode([c[:200] for c in chunks[:8]], is_query=True)
+    idx = DenseIndex(1024, "f16", keep_f32=True); idx.append(E)
+    cand, csc, _, _ = idx.search(Q, 100)
+    ex16 = orc.exact_scores_f64(orc.f16_round(E), orc.f16_round(Q))
+    ref100, _ = orc.topk_rule(ex16, 100)
+    # random-init BERT vectors are nearly collinear: many near-ties → tie-aware compare
+    for i in range(8):
+        orc.assert_topk_equivalent(cand[i], ref100[i], ex16[i], 4e-6)
+    ids, sc = idx.rescore(Q, cand, 20)
+    ex32 = orc.exact_scores_f64(E, Q)
+    for i in range(8):
+        want = cand[i][np.lexsort((cand[i], -ex32[i][cand[i]]))][:20]
+        orc.assert_topk_equivalent(ids[i], want, ex32[i], 1e-6)
+        np.testing.assert_allclose(sc[i], ex32[i][ids[i]], atol=1e-6)
+    idx.close()
