@@ -207,8 +207,10 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-    HIP_TRY(ws->flag.ensure(sizeof(int)));
-    HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    if (!ws->flag.p) {   // zeroed once; check_query_flag() re-arms it after reporting
+        HIP_TRY(ws->flag.ensure(sizeof(int)));
+        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    }
     for (int q0 = 0; q0 < nq; q0 += per_pass) {
         const int nqp = std::min(per_pass, nq - q0);
         int rc = make_geom(idx, nqp, k, true, &g);
@@ -244,7 +246,7 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         CmrScanArgs a{};
         a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
         a.lists = (u64*)ws->lists.p; a.cnt = (int*)ws->cnt.p; a.mm = (float2*)ws->mm.p;
-        if (n_levels) HIP_TRY(hipMemsetAsync(ws->tau.p, 0, (size_t)2 * NQ * 8, s));
+        a.nq = nqp;
         for (int lv = 0; lv < n_levels; ++lv) {
             const long long sp = level_panels[lv];
             const int Wl = (int)((sp + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES;
@@ -289,8 +291,10 @@ int scores_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, fl
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-    HIP_TRY(ws->flag.ensure(sizeof(int)));
-    HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    if (!ws->flag.p) {
+        HIP_TRY(ws->flag.ensure(sizeof(int)));
+        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    }
     for (int q0 = 0; q0 < nq; q0 += per_pass) {
         const int nqp = std::min(per_pass, nq - q0);
         int rc = make_geom(idx, nqp, 1, false, &g);
@@ -310,7 +314,10 @@ int check_query_flag(Workspace* ws) {
     int h = 0;
     HIP_TRY(hipMemcpyAsync(&h, ws->flag.p, sizeof(int), hipMemcpyDeviceToHost, ws->stream));
     HIP_TRY(hipStreamSynchronize(ws->stream));
-    if (h) return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+    if (h) {
+        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), ws->stream));
+        return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+    }
     return CMR_OK;
 }
 

@@ -128,10 +128,7 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 #define MERGE_THREADS 256
 #define MERGE_WAVES 4
 
-// One selection pass: every thread holds up to MERGE_PER_THREAD (+1 carried) keys in registers;
-// k rounds of {thread max, wave max (shuffles), block max via LDS} extract the k best in
-// descending order.  One barrier per round (wbest is double buffered).  Keys are unique, so
-// exactly one register in the block equals each round's winner.
+// Every thread holds up to MERGE_PER_THREAD (+1 carried) keys of the current chunk in registers.
 #define MERGE_PER_THREAD 16
 #define MERGE_POOL (MERGE_THREADS * MERGE_PER_THREAD)
 
@@ -161,24 +158,89 @@ __device__ __forceinline__ u64 cmr_wave_max_u64(u64 v) {
     return r;
 }
 
-__device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1], int k, u64* wbest, u64* res) {
+// Radix select of the k largest keys held in the block's registers (MERGE_PER_THREAD+1 per
+// thread, 0 = empty): 8 passes over the key bytes, most significant first.  Each pass histograms
+// the current digit of the keys that still match the selected prefix (256 bins = 256 threads), a
+// suffix scan finds the digit that contains the k-th largest key, and the prefix grows by one byte;
+// after the last pass the prefix IS the k-th largest key (keys are unique).  Keys >= it are
+// collected (exactly k of them) and ordered by rank counting.  Cost is independent of k.
+//   scratch: hist[256] ints, wsum[MERGE_WAVES] ints, sel[2] ints, cnt int, cand[k] u64
+__device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1], int k, int* hist, int* wsum, int* sel,
+                                                  u64* cand, u64* res) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int round = 0; round < k; ++round) {
-        u64 best = e[0];
+    // how many keys are there at all?
+    int mine = 0;
 #pragma unroll
-        for (int j = 1; j <= MERGE_PER_THREAD; ++j) best = e[j] > best ? e[j] : best;
-        const u64 wb = cmr_wave_max_u64(best);
-        u64* wbuf = wbest + (round & 1) * MERGE_WAVES;
-        if (lane == 0) wbuf[wave] = wb;
-        __syncthreads();
-        const u64 fb = cmr_wave_max_u64(lane < MERGE_WAVES ? wbuf[lane] : 0ull);
-        if (tid == 0) res[round] = fb;
-        if (fb == 0) {   // fewer than k keys in total: the rest of res stays zero (uniform exit)
-            for (int r = round + 1 + tid; r < k; r += MERGE_THREADS) res[r] = 0;
-            break;
+    for (int j = 0; j <= MERGE_PER_THREAD; ++j) mine += e[j] != 0 ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane == 0) wsum[wave] = mine;
+    if (tid == 0) sel[2] = 0;
+    for (int i = tid; i < k; i += MERGE_THREADS) { res[i] = 0; cand[i] = 0; }
+    __syncthreads();
+    int n_tot = 0;
+#pragma unroll
+    for (int w = 0; w < MERGE_WAVES; ++w) n_tot += wsum[w];
+    __syncthreads();
+
+    u64 thr = 1;   // n_tot <= k: every key qualifies
+    if (n_tot > k) {
+        u64 pval = 0, pmask = 0;
+        int k_rem = k;
+        for (int pass = 7; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            hist[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j <= MERGE_PER_THREAD; ++j) {
+                const u64 key = e[j];
+                const bool act = key != 0 && (key & pmask) == pval;
+                const int dg = (int)((key >> shift) & 255u);
+                const u64 am = __ballot(act);
+                if (am) {   // wave-uniform
+                    const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)am) - 1);
+                    const int d0 = __builtin_amdgcn_readlane(dg, first);
+                    if (__ballot(act && dg != d0) == 0) {      // all active lanes share the digit: one add
+                        if (lane == first) atomicAdd(&hist[d0], __popcll(am));
+                    } else if (act) {
+                        atomicAdd(&hist[dg], 1);
+                    }
+                }
+            }
+            __syncthreads();
+            const int c = hist[tid];
+            int s = c;     // suffix sum inside the wave: bins tid..(wave end)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(s, off);
+                if (lane + off < 64) s += o;
+            }
+            if (lane == 0) wsum[wave] = s;
+            __syncthreads();
+            int higher = 0;
+#pragma unroll
+            for (int w = 0; w < MERGE_WAVES; ++w) higher += w > wave ? wsum[w] : 0;
+            const int S = s + higher;        // keys whose digit >= tid
+            const int Sgt = S - c;           // keys whose digit >  tid
+            if (S >= k_rem && Sgt < k_rem) { sel[0] = tid; sel[1] = k_rem - Sgt; }
+            __syncthreads();
+            pval |= (u64)(unsigned)sel[0] << shift;
+            pmask |= 0xFFull << shift;
+            k_rem = sel[1];
         }
+        thr = pval;
+    }
+    // collect the winners (exactly min(k, n_tot) keys >= thr), then order them
 #pragma unroll
-        for (int j = 0; j <= MERGE_PER_THREAD; ++j) e[j] = (e[j] == fb) ? 0ull : e[j];
+    for (int j = 0; j <= MERGE_PER_THREAD; ++j)
+        if (e[j] != 0 && e[j] >= thr) cand[atomicAdd(&sel[2], 1)] = e[j];
+    __syncthreads();
+    for (int t = tid; t < k; t += MERGE_THREADS) {
+        const u64 c = cand[t];
+        if (c == 0) continue;
+        int r = 0;
+        for (int i = 0; i < k; ++i) r += cand[i] > c ? 1 : 0;
+        res[r] = c;
     }
     __syncthreads();
 }
@@ -190,11 +252,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
                                                                     float* __restrict__ out_min, float* __restrict__ out_max,
                                                                     u64* __restrict__ out_tau) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    u64* wbest = reinterpret_cast<u64*>(sm);                // 2*MERGE_WAVES
-    u64* res = wbest + 2 * MERGE_WAVES;                     // k
+    u64* cand = reinterpret_cast<u64*>(sm);                 // k
+    u64* res = cand + k;                                    // k
     int* prefix = reinterpret_cast<int*>(res + k);          // W+1
     int* wsum = prefix + (W + 1);                           // MERGE_WAVES
-    float* red = reinterpret_cast<float*>(wsum + MERGE_WAVES);  // 2*MERGE_WAVES
+    int* hist = wsum + MERGE_WAVES;                         // 256
+    int* sel = hist + 256;                                  // 4
+    float* red = reinterpret_cast<float*>(sel + 4);         // 2*MERGE_WAVES
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // exclusive prefix sum of the W list lengths
@@ -260,7 +324,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
             e[j] = v < total ? key : 0ull;
         }
         __syncthreads();     // every thread has read its carried key before the rounds rewrite res
-        merge_select_regs(e, k, wbest, res);
+        merge_select_regs(e, k, hist, wsum, sel, cand, res);
         base += MERGE_POOL;
     } while (base < total);
 
@@ -295,7 +359,7 @@ hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int n
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
                                   float* out_min, float* out_max, u64* out_tau, hipStream_t s) {
     if (W > 16 * MERGE_THREADS) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)2 * MERGE_WAVES + k) * 8 + (size_t)(W + 1) * 4 + MERGE_WAVES * 4 + 2 * MERGE_WAVES * 4;
+    const size_t lds = (size_t)2 * k * 8 + (size_t)(W + 1) * 4 + MERGE_WAVES * 4 + 256 * 4 + 4 * 4 + 2 * MERGE_WAVES * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_query_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -143,9 +143,15 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         rmax[t] = -__builtin_inff();
         tau_f[t] = -__builtin_inff();
         tau_key[t] = 0ull;
-        if (MODE == MODE_TOPK && P.tau_init) {   // a valid lower bound on the global k-th best key
-            tau_key[t] = P.tau_init[t * 32 + (lane & 31)];
-            if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
+        if (MODE == MODE_TOPK) {
+            const int q = t * 32 + (lane & 31);
+            if (q >= P.nq) {                     // padding query (all-zero operand): nothing may pass
+                tau_key[t] = ~0ull;
+                tau_f[t] = __builtin_inff();
+            } else if (P.tau_init) {             // a valid lower bound on the global k-th best key
+                tau_key[t] = P.tau_init[q];
+                if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
+            }
         }
     }
     u64* list_w = (MODE == MODE_TOPK) ? P.lists + (size_t)gw * NQ * CAP : nullptr;

@@ -106,3 +106,43 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
             if hasattr(mod, "get_similar_summaries"):
                 mod.get_similar_summaries = retrieval.get_similar_summaries
     return rag
+
+
+def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0):
+    """Rebind `MemoryPool.retrieve_similar_nodes` (utils/memory_utils.py:188-235) on ONE pool
+    instance: node embeddings live in an appendable HBM index (rows = pool order; nodes added since
+    the last call are encoded with the reference's own `compute_probe_note_embeddings` and appended —
+    BASELINE config 4's incremental append), the probe is scored against all of them in one scan.
+    Selection semantics are the reference's: cosine, descending, ties in pool order, keep
+    max(1, int(n * top_percent)).  Nodes without an embedding are skipped like the reference does."""
+    state = {"index": None, "rows": []}      # rows[i] = pool position of index row i
+    lock = threading.Lock()
+
+    def _to_np(x):
+        if hasattr(x, "detach"):
+            x = x.detach().cpu().numpy()
+        return np.asarray(x, dtype=np.float32)
+
+    def retrieve_similar_nodes(self, current_probe: str, top_percent: float = 0.5):
+        if not self.embedding_model:
+            raise ValueError("Embedding model not provided")
+        self.compute_probe_note_embeddings()
+        probe = _to_np(self.embedding_model.encode([current_probe])[0])
+        with lock:
+            have = {id(self.pool[i]) for i in state["rows"] if i < len(self.pool)}
+            fresh = [(i, n) for i, n in enumerate(self.pool) if n.embedding is not None and id(n) not in have]
+            if fresh:
+                mat = np.stack([_to_np(n.embedding) for _, n in fresh])
+                mat = mat / np.maximum(np.linalg.norm(mat, axis=1, keepdims=True), 1e-12)   # cosine == dot of unit rows
+                if state["index"] is None:
+                    state["index"] = DenseIndex(mat.shape[1], index_dtype, device=device)
+                state["index"].append(mat)
+                state["rows"].extend(i for i, _ in fresh)
+            if state["index"] is None:
+                return []
+            order = retrieval.retrieve_similar_rows(state["index"], probe, len(state["rows"]), top_percent)
+            return [self.pool[state["rows"][r]] for r in order]
+
+    pool.retrieve_similar_nodes = types.MethodType(retrieve_similar_nodes, pool)
+    pool._hip_state = state
+    return pool

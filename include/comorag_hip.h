@@ -14,6 +14,8 @@
  *  - "_dev" variants take DEVICE pointers (e.g. torch tensors' data_ptr()) and a hipStream_t
  *    passed as void* (NULL = the index's own stream); they enqueue work and return without
  *    synchronising.  Calls on one stream must not be issued concurrently from several threads.
+ *    Non-finite queries are reported (CMR_ERR_NONFINITE) by the synchronous host-buffer calls only;
+ *    the _dev calls cannot report them without a sync and leave the outputs unspecified.
  *  - handles are opaque; destroy(NULL) is a no-op.  All functions are thread-safe: searches on
  *    one index run concurrently (shared lock), append/destroy are exclusive.
  *  - there is NO CPU fallback: without a visible gfx950 device every compute call fails with

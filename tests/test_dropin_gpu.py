@@ -239,3 +239,31 @@ def test_pipelined_search_single_rank():
         assert np.array_equal(b["o_ids"].cpu().numpy(), want_i + 1000) and np.array_equal(b["o_sc"].cpu().numpy(), want_s)
     hi, hs = sh.search(Q, 20)
     assert np.array_equal(hi, want_i + 1000)
+
+
+def test_memory_pool_hook_incremental(golden_dir, fake_embedder):
+    """install_memory_pool on a MemoryPool-shaped object: same selection as the reference fixture,
+    and nodes added later are appended to the HBM index (config 4's incremental path)."""
+    import torch
+    from comorag_amd import hooks
+    m = json.load(open(os.path.join(golden_dir, "mempool.json")))
+
+    class Node:
+        def __init__(self, content):
+            self.content, self.embedding = content, None
+
+    class Pool:                                         # attribute names of utils/memory_utils.py:MemoryPool
+        def __init__(self, contents):
+            self.pool = [Node(c) for c in contents]
+            self.embedding_model = fake_embedder
+        def compute_probe_note_embeddings(self, force_recompute=False):
+            todo = [n for n in self.pool if n.embedding is None]
+            if todo:
+                for n, e in zip(todo, fake_embedder.encode([n.content for n in todo])):
+                    n.embedding = e                     # torch tensors, as BGE's encode returns
+    pool = hooks.install_memory_pool(Pool(m["contents"]))
+    sel = pool.retrieve_similar_nodes(m["probe"], top_percent=0.5)
+    assert [pool.pool.index(s) for s in sel] == m["selected"]
+    pool.pool.append(Node(m["probe"]))                  # a fused node identical to the probe text
+    sel2 = pool.retrieve_similar_nodes(m["probe"], top_percent=0.1)
+    assert len(sel2) == 1 and sel2[0] is pool.pool[-1] and len(pool._hip_state["index"]) == len(m["contents"]) + 1

@@ -97,3 +97,21 @@ def test_live_reference_agrees(tmp_path, fake_embedder):
         assert list(a.hash_ids) == list(b.hash_ids) and list(a.texts) == list(b.texts)
         assert a.hash_id_to_idx == b.hash_id_to_idx and a.hash_id_to_row == b.hash_id_to_row
     np.testing.assert_array_equal(np.asarray(a.get_embeddings(a.get_all_ids())), b.get_embeddings(b.get_all_ids()))
+
+
+def test_make_cache_embed_roundtrip(tmp_path):
+    """sqlite embedding cache (embedding_model/base.py:112-187 semantics): second call is served
+    from the file, order preserved, keyword-only call like the reference wrapper."""
+    import torch
+    from comorag_amd.embedding_model.base import make_cache_embed
+    calls = []
+    def enc(**kw):
+        calls.append(list(kw["prompts"]))
+        return torch.tensor([[float(len(p)), 1.0, 2.0] for p in kw["prompts"]])
+    f = make_cache_embed(enc, str(tmp_path / "cache.db"), "cpu")
+    a = f(prompts=["aa", "b", "cccc"], instruction="I", max_length=16)
+    b = f(prompts=["b", "zz", "aa"], instruction="I", max_length=16)
+    assert calls == [["aa", "b", "cccc"], ["zz"]]
+    assert a[:, 0].tolist() == [2.0, 1.0, 4.0] and b[:, 0].tolist() == [1.0, 2.0, 2.0]
+    c = f(prompts=["aa"], instruction="other", max_length=16)          # different instruction → different key
+    assert calls[-1] == ["aa"] and c.shape == (1, 3)
