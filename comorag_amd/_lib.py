@@ -18,6 +18,7 @@ CMR_ERR_INVALID, CMR_ERR_NO_DEVICE, CMR_ERR_HIP, CMR_ERR_OOM, CMR_ERR_NONFINITE,
 CMR_F32, CMR_BF16, CMR_F16 = 0, 1, 2
 CMR_FLAG_KEEP_F32 = 1
 CMR_MAX_K = 128
+CMR_MAX_K_2PASS = 4096
 DTYPES = {"f32": CMR_F32, "fp32": CMR_F32, "float32": CMR_F32, "bf16": CMR_BF16, "bfloat16": CMR_BF16,
           "f16": CMR_F16, "fp16": CMR_F16, "float16": CMR_F16}
 

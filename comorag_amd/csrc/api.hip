@@ -200,8 +200,31 @@ double algorithmic_bytes(const cmr_index* idx, int nq, int k) {
 }
 
 // Enqueue a full search (all passes) on ws->stream.  Device pointers in, device pointers out.
+int scores_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, float* out_dev, long long ld);
+
+// k above CMR_MAX_K (retrieve_knn's synonymy_edge_topk = 2047): materialise the scores of a block of
+// queries on the device, then select per row (radix select + ordered compaction + bitonic sort).
+int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev,
+                           float* scores_dev, float* min_dev, float* max_dev) {
+    hipStream_t s = ws->stream;
+    const long long n = idx->n;
+    const long long ld = (n + 3) / 4 * 4;
+    const int blockq = (int)std::max<long long>(1, std::min<long long>(nq, (1ll << 31) / std::max<long long>(ld * 4, 1)));  // <= 2 GiB
+    HIP_TRY(ws->d_out.ensure((size_t)blockq * ld * 4));
+    for (int q0 = 0; q0 < nq; q0 += blockq) {
+        const int nb = std::min(blockq, nq - q0);
+        int rc = scores_enqueue(idx, ws, q_dev + (size_t)q0 * idx->dim, nb, (float*)ws->d_out.p, ld);
+        if (rc) return rc;
+        HIP_TRY(cmr_launch_topk_rows((const float*)ws->d_out.p, ld, (int)n, nb, k, 0, ids_dev + (size_t)q0 * k,
+                                     scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
+                                     max_dev ? max_dev + q0 : nullptr, s));
+    }
+    return CMR_OK;
+}
+
 int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev,
                    float* min_dev, float* max_dev) {
+    if (k > CMR_MAX_K) return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
     hipStream_t s = ws->stream;
     CmrScanGeom g;
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
@@ -502,7 +525,7 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, i
                              float* min_dev, float* max_dev, void* stream) {
     if (!idx || !q_dev || !ids_dev || !scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");
     if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
-    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K);
+    if (k <= 0 || k > CMR_MAX_K_2PASS) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K_2PASS);
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     int rc = set_device(idx->device);
     if (rc) return rc;
@@ -515,7 +538,7 @@ int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k
                          float* out_min, float* out_max) {
     if (!idx || !q || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
     if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
-    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K);
+    if (k <= 0 || k > CMR_MAX_K_2PASS) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K_2PASS);
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     int rc = set_device(idx->device);
     if (rc) return rc;

@@ -402,6 +402,146 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// Large-k selection over a materialised score matrix: one workgroup per row of scores [nq, ld]
+// picks the k (<= 4096) best (score desc, column asc) — the device half of retrieve_knn's
+// torch.topk(k = 2047) (utils/embed_utils.py:56-78) once cmr_index_scores_dev produced the block.
+//   1. radix select (4 x 8 bits, MSB first) of the k-th largest order-preserving score code
+//   2. ordered stream compaction: every column with a larger code, plus the FIRST (lowest column)
+//      `need` columns with the threshold code — exactly k keys, the exported tie rule
+//   3. bitonic sort of the k keys in LDS, write ids / scores
+#define TOPK_ROWS_MAX 4096
+__device__ __forceinline__ unsigned cmr_score_code(float v) {
+    unsigned u = __float_as_uint(v + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, long long ld, int n, int k, int kpad,
+                                                        long long id_base, int64_t* __restrict__ out_ids,
+                                                        float* __restrict__ out_scores, float* __restrict__ out_min,
+                                                        float* __restrict__ out_max) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    u64* cand = reinterpret_cast<u64*>(sm);              // kpad
+    int* hist = reinterpret_cast<int*>(cand + kpad);     // 256
+    int* wsum = hist + 256;                              // 8  (2 x 4 waves)
+    int* sel = wsum + 8;                                 // 4
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = scores + (size_t)blockIdx.x * ld;
+    const int kk = k < n ? k : n;
+
+    unsigned pval = 0, pmask = 0;
+    int k_rem = kk;
+    if (n > kk) {
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += 256) {
+                const int i = i0 + tid;
+                const unsigned code = i < n ? cmr_score_code(row[i]) : 0u;
+                const bool act = i < n && (code & pmask) == pval;
+                const int dg = (int)((code >> shift) & 255u);
+                const u64 am = __ballot(act);
+                if (am) {
+                    const int first = __builtin_amdgcn_readfirstlane(__ffsll((long long)am) - 1);
+                    const int d0 = __builtin_amdgcn_readlane(dg, first);
+                    if (__ballot(act && dg != d0) == 0) { if (lane == first) atomicAdd(&hist[d0], __popcll(am)); }
+                    else if (act) atomicAdd(&hist[dg], 1);
+                }
+            }
+            __syncthreads();
+            const int c = hist[tid];
+            int s = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_down(s, off); if (lane + off < 64) s += o; }
+            if (lane == 0) wsum[wave] = s;
+            __syncthreads();
+            int higher = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) higher += w > wave ? wsum[w] : 0;
+            const int S = s + higher, Sgt = S - c;
+            if (S >= k_rem && Sgt < k_rem) { sel[0] = tid; sel[1] = k_rem - Sgt; }
+            __syncthreads();
+            pval |= (unsigned)sel[0] << shift;
+            pmask |= 0xFFu << shift;
+            k_rem = sel[1];
+        }
+    }
+    // pval = k-th largest code, k_rem = how many columns with exactly that code are needed (n <= kk: all)
+    const unsigned thr = n > kk ? pval : 0u;
+    const int need_eq = n > kk ? k_rem : n;       // (when thr = 0 every code is > thr, need_eq unused)
+    for (int i = tid; i < kpad; i += 256) cand[i] = 0;
+    __syncthreads();
+    int base_gt = 0, base_eq = 0;                 // running counts (uniform)
+    const int n_gt_total = kk - (n > kk ? need_eq : 0);
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const unsigned code = i < n ? cmr_score_code(row[i]) : 0u;
+        const bool gt = i < n && code > thr;
+        const bool eq = i < n && n > kk && code == thr;
+        // ordered positions inside this tile of 256 columns
+        const u64 bg = __ballot(gt), be = __ballot(eq);
+        const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int pg = __popcll(bg & below), pe = __popcll(be & below);
+        if (lane == 0) { wsum[wave] = __popcll(bg); wsum[4 + wave] = __popcll(be); }
+        __syncthreads();
+        int og = 0, oe = 0, tg = 0, te = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { og += w < wave ? wsum[w] : 0; oe += w < wave ? wsum[4 + w] : 0; tg += wsum[w]; te += wsum[4 + w]; }
+        const u64 key = ((u64)code << 32) | (u64)(0xFFFFFFFFu - (unsigned)i);
+        if (gt) cand[base_gt + og + pg] = key;                                  // all of them: exactly n_gt_total overall
+        if (eq) { const int slot = base_eq + oe + pe; if (slot < need_eq) cand[n_gt_total + slot] = key; }
+        base_gt += tg; base_eq += te;
+        __syncthreads();
+    }
+    // bitonic sort, descending, kpad = pow2 >= kk (zeros = empty sink to the end)
+    for (int size = 2; size <= kpad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < kpad / 2; t += 256) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const u64 a = cand[lo], b = cand[hi];
+                if ((a < b) == desc) { cand[lo] = b; cand[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        const u64 key = i < kk ? cand[i] : 0ull;
+        out_ids[(size_t)blockIdx.x * k + i] = key ? (int64_t)cmr_key_row(key) + id_base : -1;
+        out_scores[(size_t)blockIdx.x * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
+    }
+    if (out_min || out_max) {
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int i = tid; i < n; i += 256) { const float v = row[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        float* red = reinterpret_cast<float*>(wsum);
+        __syncthreads();
+        if (lane == 0) { red[wave] = mn; red[4 + wave] = mx; }
+        __syncthreads();
+        if (tid == 0) {
+            if (out_min) out_min[blockIdx.x] = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+            if (out_max) out_max[blockIdx.x] = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        }
+    }
+}
+
+hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq, int k, long long id_base,
+                                int64_t* out_ids, float* out_scores, float* out_min, float* out_max, hipStream_t s) {
+    if (k <= 0 || k > TOPK_ROWS_MAX) return hipErrorInvalidValue;
+    int kpad = 2;
+    while (kpad < (k < n ? k : n)) kpad <<= 1;
+    const size_t lds = (size_t)kpad * 8 + 256 * 4 + 8 * 4 + 4 * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(256), lds, s, scores, ld, n, k, kpad, id_base, out_ids, out_scores,
+                       out_min, out_max);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Row access in the panel-major layout.
 template <int DT>
 __device__ __forceinline__ float cmr_load_elem(const unsigned char* corpus, int ks_total, long long row, int kidx) {

@@ -57,6 +57,9 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
                                   float* out_min, float* out_max, u64* out_tau, hipStream_t s);
+// per-row top-k (k <= 4096) of a materialised score matrix [nq, ld]
+hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq, int k, long long id_base,
+                                int64_t* out_ids, float* out_scores, float* out_min, float* out_max, hipStream_t s);
 // shard merge: ids/scores [S][nq][k] -> [nq][k]
 hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int S, int nq, int k,
                                    int64_t* out_ids, float* out_scores, hipStream_t s);

@@ -100,8 +100,8 @@ def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, k
     """utils/embed_utils.py:8-97 — fp32 re-normalise both sides, exact top-k of every query over all
     keys, `{query_id: ([key ids], [scores])}`.  The reference's key-block loop + merge computes the
     global top-k, so one pass over a single HBM index gives the same answer; k <= 128 uses the fused
-    scan+top-k kernel, larger k (synonymy_edge_topk = 2047) takes the full score matrix from the GPU
-    per query block and selects on the host.  Equal scores: lower key index first (torch.topk's tie
+    scan+top-k kernel, larger k (synonymy_edge_topk = 2047, up to 4096) materialises the score block in
+    HBM and selects per row on the device; only k > 4096 falls back to a host select of GPU scores.  Equal scores: lower key index first (torch.topk's tie
     order is unspecified)."""
     if len(key_vecs) == 0:
         return {}
@@ -112,10 +112,10 @@ def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, k
         index.append(kx)
         kk = min(k, len(kx))
         results: Dict[str, Tuple[List[str], List[float]]] = {}
-        from ._lib import CMR_MAX_K
+        from ._lib import CMR_MAX_K_2PASS
         for s in range(0, len(q), query_batch_size):
             qb = q[s:s + query_batch_size]
-            if kk <= CMR_MAX_K:
+            if kk <= CMR_MAX_K_2PASS:      # fused kernel (k <= 128) or device scores + per-row select
                 ids, sc, _, _ = index.search(qb, kk, with_minmax=False)
             else:
                 full = index.scores(qb)
@@ -137,8 +137,7 @@ def retrieve_similar_rows(index: DenseIndex, probe_embedding, n_nodes: int, top_
     max(1, int(n*top_percent)), ties keep pool order (the reference's stable sort)."""
     p = _l2n(_as_query(probe_embedding))
     keep = max(1, int(n_nodes * top_percent))
-    ids, _, _, _ = index.search(p, min(keep, 128), with_minmax=False) if keep <= 128 else (None, None, None, None)
-    if ids is None:
-        s = index.scores(p)[0]
-        return np.argsort(-s, kind="stable")[:keep].tolist()
-    return ids[0].tolist()
+    if keep <= 4096:
+        return index.search(p, keep, with_minmax=False)[0][0].tolist()
+    s = index.scores(p)[0]
+    return np.argsort(-s, kind="stable")[:keep].tolist()

@@ -52,7 +52,9 @@ enum cmr_dtype { CMR_F32 = 0, CMR_BF16 = 1, CMR_F16 = 2 };
 /* index flags */
 #define CMR_FLAG_KEEP_F32 1u /* also keep a row-major fp32 shadow (exact re-score, C5) */
 
-#define CMR_MAX_K 128 /* largest k served by the fused scan+top-k kernel */
+#define CMR_MAX_K 128        /* largest k served by the fused scan+top-k kernel */
+#define CMR_MAX_K_2PASS 4096 /* largest k overall: above CMR_MAX_K the scores of a query block are
+                                materialised in HBM and selected per row (retrieve_knn's k = 2047) */
 
 typedef struct cmr_index cmr_index_t;
 
@@ -92,7 +94,7 @@ int32_t cmr_index_append_dev(cmr_index_t* idx, const float* rows_f32_dev, int64_
  * (ComoRAG.py:950-967), get_fact_scores + link_top_k argsort (ComoRAG.py:937-948,1073),
  * get_similar_summaries (utils/embed_utils.py:152-158), the python-loop cosine of
  * MemoryPool.retrieve_similar_nodes (utils/memory_utils.py:213-227) and each
- * torch.mm + torch.topk block of retrieve_knn (utils/embed_utils.py:52-78) for k <= CMR_MAX_K.
+ * torch.mm + torch.topk block of retrieve_knn (utils/embed_utils.py:52-78); k <= CMR_MAX_K_2PASS.
  *   q        [nq, dim] fp32 (rounded to the index dtype for bf16/f16 indexes, as BASELINE.md §2)
  *   out_ids  [nq, k] int64 row ids, -1 padded when the index has < k rows
  *   out_scores [nq, k] fp32 raw inner products, descending, -inf padded

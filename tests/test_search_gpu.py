@@ -78,6 +78,25 @@ def test_k_values(k):
     _check("bf16", X, Q, k)
 
 
+@pytest.mark.parametrize("dtype,n,k", [("bf16", 5000, 129), ("bf16", 5000, 2047), ("f32", 3000, 500), ("bf16", 4097, 4096),
+                                       ("bf16", 300, 2047), ("f16", 70000, 1000)])
+def test_large_k_two_pass(dtype, n, k):
+    """k above CMR_MAX_K: device score block + per-row radix select / ordered compaction / bitonic sort."""
+    X, Q = _mk(n, 64, 7, seed=n + k)
+    X[n // 2] = X[3]; X[n - 1] = X[3]                 # ties straddling the selection threshold region
+    Q[0] = X[3]
+    _check(dtype, X, Q, k)
+
+
+def test_large_k_all_equal_rows():
+    from comorag_amd.index import DenseIndex
+    X = np.tile(orc.synthetic_corpus(1, 32, seed=1), (1000, 1))
+    idx = DenseIndex(32, "bf16"); idx.append(X)
+    ids, sc, mn, mx = idx.search(X[:2], 300)
+    assert ids[0].tolist() == list(range(300)) and ids[1].tolist() == list(range(300)) and mn[0] == mx[0]
+    idx.close()
+
+
 @pytest.mark.parametrize("env", [{"CMR_SCAN_ASM_RING": "0"}, {"CMR_SCAN_ASM_RING": "0", "CMR_SCAN_RING": "8"},
                                  {"CMR_SCAN_RING": "8"}, {"CMR_SCAN_RING": "16"}, {"CMR_SCAN_GRID": "3"}])
 def test_ring_variants_agree(env):
