@@ -74,15 +74,17 @@ def build_shard(torch, args, rows, rank, world, device, keep_host=None):
 
 def run_steps(torch, dist, sh, q, k, steps, warmup, world, device):
     for i in range(warmup):
-        sh.search_pipelined(q, k, i & 1)
+        sh.search_pipelined(q, k, i & 1)["done"].synchronize()
     torch.cuda.synchronize(device)
     sh.local.profile(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
+    last = None
     for i in range(steps):
-        sh.search_pipelined(q, k, i & 1)
+        last = sh.search_pipelined(q, k, i & 1)
+    last["done"].synchronize()
     torch.cuda.synchronize(device)
     if world > 1:
         dist.barrier()

@@ -72,17 +72,21 @@ struct DevBuf {
 struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf qfrag, lists, cnt, mm, part, flag, tau;
+    DevBuf qfrag, lists, cnt, mm, part, flag, tau, s_lists, s_cnt, s_mm;
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
     void release() {
         qfrag.release(); lists.release(); cnt.release(); mm.release(); part.release(); flag.release(); tau.release();
+        s_lists.release(); s_cnt.release(); s_mm.release();
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
 
 struct ProfEvent { hipEvent_t a, b; };
+
+struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullptr, main_done = nullptr; bool used = false; };
+struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sq = nullptr; PipeSlot slot[2]; unsigned next = 0; };
 
 }  // namespace
 
@@ -111,6 +115,10 @@ struct cmr_index {
     int force_asm = -1;      // CMR_SCAN_ASM_RING=0|1
     int force_grid = 0;      // CMR_SCAN_GRID
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
+    long long id_base = 0;   // added to every returned row id (global ids of a row shard)
+    int reserve_cus = 96;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves to the next pass's pre-phase (160 CUs still saturate HBM)
+    std::mutex pipe_mu;
+    Pipe pipe;
     size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
 };
 
@@ -215,96 +223,161 @@ int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, in
         const int nb = std::min(blockq, nq - q0);
         int rc = scores_enqueue(idx, ws, q_dev + (size_t)q0 * idx->dim, nb, (float*)ws->d_out.p, ld);
         if (rc) return rc;
-        HIP_TRY(cmr_launch_topk_rows((const float*)ws->d_out.p, ld, (int)n, nb, k, 0, ids_dev + (size_t)q0 * k,
+        HIP_TRY(cmr_launch_topk_rows((const float*)ws->d_out.p, ld, (int)n, nb, k, idx->id_base, ids_dev + (size_t)q0 * k,
                                      scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                                      max_dev ? max_dev + q0 : nullptr, s));
     }
     return CMR_OK;
 }
 
-int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev,
-                   float* min_dev, float* max_dev) {
-    if (k > CMR_MAX_K) return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
-    hipStream_t s = ws->stream;
+// One pass (<= 64 queries) of the fused search.  The pre-phase (query packing + sampling levels)
+// goes to `sp`, the main scan + candidate merge to `sm`; when the two differ (pipelined mode) an
+// event orders them, so the pre-phase of the NEXT pass/batch can overlap this pass's main scan.
+int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, hipStream_t sq, hipEvent_t ev_pre, hipEvent_t ev_scan,
+                 const float* q_dev, int nqp,
+                 int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev) {
     CmrScanGeom g;
-    const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
-    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
     if (!ws->flag.p) {   // zeroed once; check_query_flag() re-arms it after reporting
         HIP_TRY(ws->flag.ensure(sizeof(int)));
-        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), sp));
     }
+    int rc = make_geom(idx, nqp, k, true, &g);
+    if (rc) return rc;
+    if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+    const int NQ = g.nqt * 32;
+    const int W = g.grid * CMR_SCAN_WAVES;
+    // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
+    // best of that sample per query as the threshold of the next level / of the main scan.  Any
+    // subset's k-th best is a valid lower bound of the global k-th best, so results are unchanged;
+    // what changes is that only ~S_{i+1}*k/S_i scores per query ever reach the candidate lists
+    // (instead of k*ln(rows/k) per wave and query), which keeps every merge at a few thousand keys.
+    //   S0 = max(512, 32k) rows, S1 = clamp(N/32, 8*S0, 128*S0) rows (only when N >= 128 Ki rows)
+    long long level_panels[2] = {0, 0};
+    int n_levels = 0;
+    if (!idx->no_sample && npanels >= 256) {
+        const long long s0 = std::max<long long>(16, k);                       // panels
+        level_panels[n_levels++] = s0;
+        if (npanels >= 4096) {
+            const long long s1 = std::min<long long>(std::max<long long>(npanels / 32, 8 * s0), 128 * s0);
+            if (s1 < npanels / 2) level_panels[n_levels++] = s1;
+        }
+    }
+    const long long max_sample = std::max(level_panels[0], level_panels[1]);
+    const int Ws = max_sample ? (int)((max_sample + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES : 0;
+    // sample passes and the main pass use separate list buffers: in pipelined mode the next batch's
+    // sampling runs while this batch's main scan still owns `lists`
+    HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
+    HIP_TRY(ws->lists.ensure((size_t)W * NQ * g.cap * 8));
+    HIP_TRY(ws->cnt.ensure((size_t)W * NQ * 4));
+    HIP_TRY(ws->mm.ensure((size_t)W * NQ * 8));
+    if (Ws) {
+        HIP_TRY(ws->s_lists.ensure((size_t)Ws * NQ * g.cap * 8));
+        HIP_TRY(ws->s_cnt.ensure((size_t)Ws * NQ * 4));
+        HIP_TRY(ws->s_mm.ensure((size_t)Ws * NQ * 8));
+    }
+    HIP_TRY(ws->tau.ensure((size_t)2 * NQ * 8));
+    HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p, (int*)ws->flag.p, sp));
+    CmrScanArgs a{};
+    a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
+    a.nq = nqp;
+    for (int lv = 0; lv < n_levels; ++lv) {
+        const long long spn = level_panels[lv];
+        const int Wl = (int)((spn + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES;
+        CmrScanGeom gs = g;
+        gs.grid = Wl / CMR_SCAN_WAVES;
+        CmrScanArgs as = a;
+        as.lists = (u64*)ws->s_lists.p; as.cnt = (int*)ws->s_cnt.p; as.mm = (float2*)ws->s_mm.p;
+        as.sample_waves = (int)spn; as.sample_stride = (int)(npanels / spn);
+        u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
+        HIP_TRY(cmr_launch_scan_topk(gs, as, sp));
+        HIP_TRY(cmr_launch_merge_query((const u64*)ws->s_lists.p, (const int*)ws->s_cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
+                                       nullptr, nullptr, nullptr, tau_out, sp));
+        a.tau_init = tau_out;
+    }
+    if (sp != sm) {
+        HIP_TRY(hipEventRecord(ev_pre, sp));
+        HIP_TRY(hipStreamWaitEvent(sm, ev_pre, 0));
+    }
+    a.lists = (u64*)ws->lists.p; a.cnt = (int*)ws->cnt.p; a.mm = (float2*)ws->mm.p;
+    ProfEvent pe{};
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> pg(idx->prof_mu);
+        prof = idx->prof_on;
+    }
+    if (prof) {
+        HIP_TRY(hipEventCreate(&pe.a));
+        HIP_TRY(hipEventCreate(&pe.b));
+        HIP_TRY(hipEventRecord(pe.a, sm));
+    }
+    HIP_TRY(cmr_launch_scan_topk(g, a, sm));
+    if (prof) {
+        HIP_TRY(hipEventRecord(pe.b, sm));
+        std::lock_guard<std::mutex> pg(idx->prof_mu);
+        idx->prof_events.push_back(pe);
+        idx->prof_bytes = algorithmic_bytes(idx, nqp, k);
+    }
+    if (sq != sm) {   // pipelined: the candidate merge leaves the scan stream so the next main scan starts at once
+        HIP_TRY(hipEventRecord(ev_scan, sm));
+        HIP_TRY(hipStreamWaitEvent(sq, ev_scan, 0));
+    }
+    HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, (const float2*)ws->mm.p,
+                                   idx->id_base, ids_dev, scores_dev, min_dev, max_dev, nullptr, sq));
+    return CMR_OK;
+}
+
+int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev,
+                   float* min_dev, float* max_dev) {
+    if (k > CMR_MAX_K) return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
+    const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
+    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     for (int q0 = 0; q0 < nq; q0 += per_pass) {
         const int nqp = std::min(per_pass, nq - q0);
-        int rc = make_geom(idx, nqp, k, true, &g);
+        int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
+                              ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
+                              max_dev ? max_dev + q0 : nullptr);
         if (rc) return rc;
-        const int NQ = g.nqt * 32;
-        const int W = g.grid * CMR_SCAN_WAVES;
-        // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
-        // best of that sample per query as the threshold of the next level / of the main scan.  Any
-        // subset's k-th best is a valid lower bound of the global k-th best, so results are unchanged;
-        // what changes is that only ~S_{i+1}*k/S_i scores per query ever reach the candidate lists
-        // (instead of k*ln(rows/k) per wave and query), which keeps every merge at a few thousand keys.
-        //   S0 = max(512, 32k) rows, S1 = clamp(N/32, 8*S0, 128*S0) rows (only when N >= 128 Ki rows)
-        long long level_panels[2] = {0, 0};
-        int n_levels = 0;
-        if (!idx->no_sample && npanels >= 256) {
-            const long long s0 = std::max<long long>(16, k);                       // panels
-            level_panels[n_levels++] = s0;
-            if (npanels >= 4096) {
-                const long long s1 = std::min<long long>(std::max<long long>(npanels / 32, 8 * s0), 128 * s0);
-                if (s1 < npanels / 2) level_panels[n_levels++] = s1;
-            }
-        }
-        long long max_sample = std::max(level_panels[0], level_panels[1]);
-        const int Ws = max_sample ? (int)((max_sample + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES : 0;
-        const int Wmax = std::max(W, Ws);
-        HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
-        HIP_TRY(ws->lists.ensure((size_t)Wmax * NQ * g.cap * 8));
-        HIP_TRY(ws->cnt.ensure((size_t)Wmax * NQ * 4));
-        HIP_TRY(ws->mm.ensure((size_t)Wmax * NQ * 8));
-        HIP_TRY(ws->tau.ensure((size_t)2 * NQ * 8));
-        HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev + (size_t)q0 * idx->dim, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p,
-                                        (int*)ws->flag.p, s));
-        CmrScanArgs a{};
-        a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
-        a.lists = (u64*)ws->lists.p; a.cnt = (int*)ws->cnt.p; a.mm = (float2*)ws->mm.p;
-        a.nq = nqp;
-        for (int lv = 0; lv < n_levels; ++lv) {
-            const long long sp = level_panels[lv];
-            const int Wl = (int)((sp + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES;
-            CmrScanGeom gs = g;
-            gs.grid = Wl / CMR_SCAN_WAVES;
-            CmrScanArgs as = a;
-            as.sample_waves = (int)sp; as.sample_stride = (int)(npanels / sp);
-            u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
-            HIP_TRY(cmr_launch_scan_topk(gs, as, s));
-            HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
-                                           nullptr, nullptr, nullptr, tau_out, s));
-            a.tau_init = tau_out;
-        }
-        ProfEvent pe{};
-        bool prof = false;
-        {
-            std::lock_guard<std::mutex> pg(idx->prof_mu);
-            prof = idx->prof_on;
-        }
-        if (prof) {
-            HIP_TRY(hipEventCreate(&pe.a));
-            HIP_TRY(hipEventCreate(&pe.b));
-            HIP_TRY(hipEventRecord(pe.a, s));
-        }
-        HIP_TRY(cmr_launch_scan_topk(g, a, s));
-        if (prof) {
-            HIP_TRY(hipEventRecord(pe.b, s));
-            std::lock_guard<std::mutex> pg(idx->prof_mu);
-            idx->prof_events.push_back(pe);
-            idx->prof_bytes = algorithmic_bytes(idx, nqp, k);
-        }
-        HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, (const float2*)ws->mm.p, 0,
-                                       ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k,
-                                       min_dev ? min_dev + q0 : nullptr, max_dev ? max_dev + q0 : nullptr, nullptr, s));
     }
+    return CMR_OK;
+}
+
+// Pipelined search: three internal streams.  Pre-phases run on `sp` back to back, candidate merges
+// on `sq`; main scans are serialised on `sm` (two HBM-bound scans at once only slow each other down) and leave
+// `reserve_cus` CUs free, on which the next pass's sampling scans and the merges run concurrently.
+int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev, float* min_dev,
+                             float* max_dev, hipEvent_t wait_event, hipEvent_t* done_event) {
+    std::lock_guard<std::mutex> pl(idx->pipe_mu);
+    Pipe& P = idx->pipe;
+    if (!P.sp) {
+        HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].scan_done, hipEventDisableTiming));
+            P.slot[i].ws.stream = P.sm;
+        }
+    }
+    if (wait_event) HIP_TRY(hipStreamWaitEvent(P.sp, wait_event, 0));
+    if (k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "pipelined search supports k <= %d", CMR_MAX_K);
+    const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
+    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
+    PipeSlot* last = nullptr;
+    for (int q0 = 0; q0 < nq; q0 += per_pass) {
+        const int nqp = std::min(per_pass, nq - q0);
+        PipeSlot* sl = &P.slot[P.next++ & 1];
+        if (sl->used) HIP_TRY(hipStreamWaitEvent(P.sp, sl->main_done, 0));   // its buffers are free again
+        int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, q_dev + (size_t)q0 * idx->dim, nqp, k, idx->reserve_cus,
+                              ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
+                              max_dev ? max_dev + q0 : nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(sl->main_done, P.sq));
+        sl->used = true;
+        last = sl;
+    }
+    if (done_event) *done_event = last ? last->main_done : nullptr;
     return CMR_OK;
 }
 
@@ -432,6 +505,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_asm = env_int("CMR_SCAN_ASM_RING", -1);
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
+    idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", 96);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);
@@ -453,6 +527,16 @@ int32_t cmr_index_destroy(cmr_index_t* idx) {
         for (Workspace* w : idx->free_ws) { w->release(); delete w; }
         for (auto& kv : idx->stream_ws) { kv.second->release(); delete kv.second; }
         for (ProfEvent& pe : idx->prof_events) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+        for (int i = 0; i < 2; ++i) {
+            idx->pipe.slot[i].ws.stream = nullptr;
+            idx->pipe.slot[i].ws.release();
+            if (idx->pipe.slot[i].pre_done) (void)hipEventDestroy(idx->pipe.slot[i].pre_done);
+            if (idx->pipe.slot[i].main_done) (void)hipEventDestroy(idx->pipe.slot[i].main_done);
+            if (idx->pipe.slot[i].scan_done) (void)hipEventDestroy(idx->pipe.slot[i].scan_done);
+        }
+        if (idx->pipe.sp) (void)hipStreamDestroy(idx->pipe.sp);
+        if (idx->pipe.sm) (void)hipStreamDestroy(idx->pipe.sm);
+        if (idx->pipe.sq) (void)hipStreamDestroy(idx->pipe.sq);
         idx->stage.release();
         if (idx->corpus) (void)hipFree(idx->corpus);
         if (idx->shadow) (void)hipFree(idx->shadow);
@@ -532,6 +616,60 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, i
     Workspace* ws = acquire_ws(idx, (hipStream_t)stream, true);
     if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
     return search_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
+}
+
+int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_dev, int32_t nq, int32_t k, int64_t* ids_dev, float* scores_dev,
+                                   float* min_dev, float* max_dev, void* wait_event, void** done_event) {
+    if (!idx || !q_dev || !ids_dev || !scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K);
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    hipEvent_t done = nullptr;
+    rc = search_pipelined_enqueue(idx, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev, (hipEvent_t)wait_event, &done);
+    if (done_event) *done_event = (void*)done;
+    return rc;
+}
+
+int32_t cmr_index_set_id_base(cmr_index_t* idx, int64_t base) {
+    if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    idx->id_base = base;
+    return CMR_OK;
+}
+
+int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream) {
+    if (!idx || !stream) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (which < 0 || which > 2) return fail(CMR_ERR_INVALID, "which must be 0 (pre), 1 (scan) or 2 (post)");
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> pl(idx->pipe_mu);
+    Pipe& P = idx->pipe;
+    if (!P.sp) {
+        HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].scan_done, hipEventDisableTiming));
+        }
+    }
+    *stream = which == 0 ? (void*)P.sp : which == 1 ? (void*)P.sm : (void*)P.sq;
+    return CMR_OK;
+}
+
+int32_t cmr_stream_wait_event(void* stream, void* event) {
+    if (!event) return CMR_OK;
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return CMR_OK;
+}
+
+int32_t cmr_event_synchronize(void* event) {
+    if (!event) return CMR_OK;
+    HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+    return CMR_OK;
 }
 
 int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,

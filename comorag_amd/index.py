@@ -117,6 +117,40 @@ class DenseIndex:
             C.c_void_p(out_max.data_ptr()) if out_max is not None else None, C.c_void_p(stream)))
         return out_ids, out_scores
 
+    def search_pipelined(self, q_t, k: int, out_ids, out_scores, out_min=None, out_max=None, wait_event=None):
+        """Throughput mode (cmr_index_search_pipelined): enqueue on the index's own two streams and
+        return an opaque done-event handle.  `wait_event`: a torch.cuda.Event (inputs ready) or None.
+        Use `wait(handle, stream)` / `sync(handle)` before reading the outputs."""
+        import torch
+        assert q_t.is_cuda and q_t.dtype == torch.float32 and q_t.is_contiguous() and q_t.shape[1] == self.dim
+        done = C.c_void_p()
+        we = C.c_void_p(wait_event.cuda_event) if wait_event is not None else None
+        L.check(L.lib().cmr_index_search_pipelined(
+            self._h, C.c_void_p(q_t.data_ptr()), q_t.shape[0], k, C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_scores.data_ptr()),
+            C.c_void_p(out_min.data_ptr()) if out_min is not None else None,
+            C.c_void_p(out_max.data_ptr()) if out_max is not None else None, we, C.byref(done)))
+        return done
+
+    def set_id_base(self, base: int) -> None:
+        """Offset added to every returned row id (global id of local row 0 of a row shard)."""
+        L.check(L.lib().cmr_index_set_id_base(self._h, int(base)))
+
+    def pipeline_stream(self, which: int = 2):
+        """The pipeline's pre / scan / post stream as a torch.cuda.ExternalStream."""
+        import torch
+        s = C.c_void_p()
+        L.check(L.lib().cmr_index_pipeline_stream(self._h, which, C.byref(s)))
+        return torch.cuda.ExternalStream(s.value, device=torch.device("cuda", self.device))
+
+    @staticmethod
+    def wait(done_handle, torch_stream) -> None:
+        """Make a torch stream wait for a pipelined search's outputs."""
+        L.check(L.lib().cmr_stream_wait_event(C.c_void_p(torch_stream.cuda_stream), done_handle))
+
+    @staticmethod
+    def sync(done_handle) -> None:
+        L.check(L.lib().cmr_event_synchronize(done_handle))
+
     def scores(self, q) -> np.ndarray:
         """All raw scores [nq, N] (fp32)."""
         q = _f32c(q)

@@ -34,7 +34,9 @@ class ShardedIndex:
             from .index import DenseIndex
             index = DenseIndex(dim, dtype, device=device, capacity_hint=capacity_hint)
         self.local = index
-        self._side = None
+        if hasattr(index, "set_id_base"):
+            index.set_id_base(self.base)        # the library returns global ids from here on
+        self._post = None
         self._bufs = {}
 
     def __len__(self):
@@ -47,13 +49,16 @@ class ShardedIndex:
         import torch
         import torch.distributed as dist
         from .index import merge_topk
-        fn = local_search or (lambda qq, kk: self.local.search(qq, kk, with_minmax=False)[:2])
-        ids, sc = fn(q, k)
+        if local_search is not None:            # CPU-only tests: shard-local ids from the stand-in
+            ids, sc = local_search(q, k)
+            ids = np.where(ids >= 0, ids + self.base, -1)
+        else:                                   # HIP scan: ids are already global (cmr_index_set_id_base)
+            ids, sc = self.local.search(q, k, with_minmax=False)[:2]
         nq = q.shape[0]
         pid = np.full((nq, k), -1, dtype=np.int64)
         psc = np.full((nq, k), -np.inf, dtype=np.float32)
         kk = ids.shape[1]
-        pid[:, :kk] = np.where(ids >= 0, ids + self.base, -1)
+        pid[:, :kk] = ids
         psc[:, :kk] = sc
         if self.world == 1:
             return merge_topk(pid[None], psc[None])
@@ -77,54 +82,60 @@ class ShardedIndex:
                 sc=torch.empty((nq, k), dtype=torch.float32, device=dev),
                 g_ids=torch.empty((self.world * nq, k), dtype=torch.int64, device=dev),    # == [world, nq, k]
                 g_sc=torch.empty((self.world * nq, k), dtype=torch.float32, device=dev),
-                o_ids=torch.empty((nq, k), dtype=torch.int64, device=dev),
-                o_sc=torch.empty((nq, k), dtype=torch.float32, device=dev),
-                done=torch.cuda.Event(), scanned=torch.cuda.Event(), used=False)
+                o_ids=None, o_sc=None, done=None)
+            b = self._bufs[key]
+            if self.world > 1:
+                b["o_ids"] = torch.empty((nq, k), dtype=torch.int64, device=dev)
+                b["o_sc"] = torch.empty((nq, k), dtype=torch.float32, device=dev)
+            else:
+                b["o_ids"], b["o_sc"] = b["ids"], b["sc"]
         return self._bufs[key]
 
-    def search_pipelined(self, q_t, k: int, slot: int):
-        """Enqueue one batch without blocking the host.  Buffers are double buffered (`slot` 0/1,
-        alternate between consecutive batches):
-          scan stream : query packing, sampling passes, the corpus scan, per-shard candidate merge
-          side stream : RCCL all-gather of the [B,k] candidates + final shard merge (per slot)
-        so the latency-bound collective + shard merge of batch i overlap the HBM-bound scan of
-        batch i+1.  Returns the slot's buffer dict; `o_ids`/`o_sc` (global ids / raw scores) are
-        valid after `bufs['done']` (a torch.cuda.Event)."""
+    def search_pipelined(self, q_t, k: int, slot: int, q_ready=None):
+        """Enqueue one batch without blocking the host; alternate `slot` (0/1) between consecutive
+        batches.  The index's own pipeline (cmr_index_search_pipelined) overlaps query packing +
+        sampling passes of batch i+1 with the HBM-bound main scan of batch i (main scans serialised);
+        row ids come out global (`cmr_index_set_id_base`).  For world > 1 the RCCL all-gather of the
+        [B,k] candidates and the shard merge are enqueued on the pipeline's post stream, i.e. ordered
+        after this batch's outputs and before the slot's buffers are rewritten — no extra streams or
+        events (HIP multiplexes streams onto a few in-order hardware queues; every additional stream
+        with wait packets risks blocking the scan queue: measured 429 vs 323 us/step).
+        Returns the slot's buffers: `o_ids` / `o_sc` are valid after `done.synchronize()`.
+        `q_t` must already be materialised on the device, or pass `q_ready` (a torch.cuda.Event
+        recorded on a non-default stream; a null-stream event would serialise the batches)."""
         import ctypes as C
         import torch
         import torch.distributed as dist
         dev = q_t.device
         nq = q_t.shape[0]
         b = self._buffers(slot, nq, k, dev)
-        caller = torch.cuda.current_stream(dev)
-        if self._side is None:
-            # ONE scan stream: two HBM-bound scans in flight at once only slow each other down
-            # (measured: 2-stream scans 0.68 ms/step vs 0.43 ms/step serial at 1 M rows).
-            sc = torch.cuda.Stream(device=dev)
-            self._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-            self._scan = [sc, sc]
-        scan, side = self._scan[slot], self._side[slot]
-        ready = torch.cuda.Event()
-        ready.record(caller)                      # q_t produced on the caller's stream
-        scan.wait_event(ready)
-        if b["used"]:
-            scan.wait_event(b["done"])            # slot reuse: its previous merge has consumed ids/sc
-        with torch.cuda.stream(scan):
-            self.local.search_dev(q_t, k, out_ids=b["ids"], out_scores=b["sc"], stream=scan.cuda_stream)
-            if self.base:
-                b["ids"].add_(self.base * (b["ids"] >= 0))
-            b["scanned"].record(scan)
-        with torch.cuda.stream(side):
-            side.wait_event(b["scanned"])
-            if self.world > 1:
+        handle = self.local.search_pipelined(q_t, k, b["ids"], b["sc"], wait_event=q_ready)
+        if self.world > 1:
+            if self._post is None:
+                self._post = self.local.pipeline_stream(2)
+            with torch.cuda.stream(self._post):
                 dist.all_gather_into_tensor(b["g_ids"], b["ids"], group=self.group)
                 dist.all_gather_into_tensor(b["g_sc"], b["sc"], group=self.group)
                 L.check(L.lib().cmr_merge_topk_dev(
                     self.device, C.c_void_p(b["g_ids"].data_ptr()), C.c_void_p(b["g_sc"].data_ptr()), self.world, nq, k,
-                    C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), C.c_void_p(side.cuda_stream)))
-            else:
-                b["o_ids"].copy_(b["ids"], non_blocking=True)
-                b["o_sc"].copy_(b["sc"], non_blocking=True)
-            b["done"].record(side)
-        b["used"] = True
+                    C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), C.c_void_p(self._post.cuda_stream)))
+                ev = torch.cuda.Event()
+                ev.record(self._post)
+            b["done"] = ev
+        else:
+            b["done"] = _Done(self.local, handle)
         return b
+
+
+class _Done:
+    """Completion handle of a pipelined batch on a single shard (wraps the index's hipEvent)."""
+
+    def __init__(self, index, handle):
+        self._index, self._h = index, handle
+
+    def synchronize(self):
+        self._index.sync(self._h)
+
+    def wait(self, stream=None):
+        import torch
+        self._index.wait(self._h, stream or torch.cuda.current_stream())

@@ -105,6 +105,30 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t n
                              int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
                              float* out_max_dev, void* stream);
 
+/* Throughput mode for a stream of independent query batches (serving; bench.py).  Work is enqueued
+ * on two streams owned by the index: query packing + sampling passes of batch i+1 overlap the
+ * HBM-bound main scan of batch i (main scans themselves are serialised and leave a few CUs free
+ * for that).  wait_event (hipEvent_t or NULL): inputs are ready when it completes.  *done_event
+ * (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded two
+ * pipelined calls later, so wait on it (hipStreamWaitEvent / hipEventSynchronize) before then.
+ * k <= CMR_MAX_K.  Results are identical to cmr_index_search_dev.                               */
+int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
+                                   int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
+                                   float* out_max_dev, void* wait_event, void** done_event);
+
+/* Row-shard support: every row id returned by the search entry points is offset by `base` (the
+ * global id of local row 0), so per-shard candidates can be all-gathered and merged as they are.  */
+int32_t cmr_index_set_id_base(cmr_index_t* idx, int64_t base);
+/* The pipeline's streams (which = 0 pre-phase, 1 main scans, 2 candidate merges / outputs) as
+ * hipStream_t.  Work enqueued on stream 2 after a pipelined call is ordered after that call's
+ * outputs and before the next use of the same output buffers (the RCCL exchange goes there).     */
+int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream);
+
+/* Helpers for callers that only hold opaque handles (e.g. a torch stream's cuda_stream):
+ * make `stream` (hipStream_t) wait for `event` (hipEvent_t from *done_event), or block the host.  */
+int32_t cmr_stream_wait_event(void* stream, void* event);
+int32_t cmr_event_synchronize(void* event);
+
 /* All N raw scores per query, out [nq, ld] fp32 (ld >= N; ld = N when 0).  For the callers that
  * consume every score: graph_search_with_fact_entities reads all (id, score) pairs of
  * dense_passage_retrieval (ComoRAG.py:1034-1042) and get_fact_scores returns the full vector

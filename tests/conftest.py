@@ -18,11 +18,10 @@ def pytest_configure(config):
 
 
 def _has_gpu() -> bool:
-    try:
-        from comorag_amd import _lib as L
-        return L.device_count() > 0
-    except Exception:
-        return False
+    # A missing / stale libcomorag_hip.so must FAIL the run (ImportError / AttributeError propagate),
+    # never silently skip the GPU tests; only "no device visible" skips them.
+    from comorag_amd import _lib as L
+    return L.device_count() > 0
 
 
 def pytest_collection_modifyitems(config, items):

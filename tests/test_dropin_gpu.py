@@ -225,45 +225,46 @@ def test_logical_shards_equal_single_index(S):
     one.close()
 
 
+def test_index_pipelined_equals_plain():
+    import torch
+    from comorag_amd.index import DenseIndex
+    X = orc.synthetic_corpus(300_000, 128, seed=51)
+    idx = DenseIndex(128, "bf16"); idx.append(X)
+    for nq in (5, 64, 130):                                   # 130 = three passes, each its own pipeline slot
+        Q = orc.synthetic_queries(nq, 128, seed=nq, planted=X)
+        wi, ws, wmn, wmx = idx.search(Q, 20)
+        q = torch.from_numpy(Q).cuda()
+        res = []
+        for i in range(4):                                    # back-to-back batches, alternating output buffers
+            oi = torch.empty((nq, 20), dtype=torch.int64, device="cuda"); os_ = torch.empty((nq, 20), dtype=torch.float32, device="cuda")
+            mn = torch.empty(nq, device="cuda"); mx = torch.empty(nq, device="cuda")
+            h = idx.search_pipelined(q, 20, oi, os_, mn, mx)
+            res.append((h, oi, os_, mn, mx))
+        for h, oi, os_, mn, mx in res:
+            idx.sync(h)
+            assert np.array_equal(oi.cpu().numpy(), wi) and np.array_equal(os_.cpu().numpy(), ws)
+            assert np.array_equal(mn.cpu().numpy(), wmn) and np.array_equal(mx.cpu().numpy(), wmx)
+    idx.close()
+
+
 def test_pipelined_search_single_rank():
     import torch
+    from comorag_amd.index import DenseIndex
     from comorag_amd.sharded import ShardedIndex
     X = orc.synthetic_corpus(50_000, 128, seed=41); Q = orc.synthetic_queries(16, 128, seed=42, planted=X)
-    sh = ShardedIndex(128, "bf16", base=1000)
+    plain = DenseIndex(128, "bf16"); plain.append(X)
+    want_i, want_s, _, _ = plain.search(Q, 20)
+    sh = ShardedIndex(128, "bf16", base=1000)                 # the library offsets row ids by the shard base
     sh.local.append(X)
-    want_i, want_s, _, _ = sh.local.search(Q, 20)
     q = torch.from_numpy(Q).cuda()
-    outs = [sh.search_pipelined(q, 20, i & 1) for i in range(5)]
     torch.cuda.synchronize()
-    for b in outs[-2:]:
-        assert np.array_equal(b["o_ids"].cpu().numpy(), want_i + 1000) and np.array_equal(b["o_sc"].cpu().numpy(), want_s)
+    outs = []
+    for i in range(5):
+        b = sh.search_pipelined(q, 20, i & 1)
+        b["done"].synchronize()
+        outs.append((b["o_ids"].cpu().numpy().copy(), b["o_sc"].cpu().numpy().copy()))
+    for oi, os_ in outs:
+        assert np.array_equal(oi, want_i + 1000) and np.array_equal(os_, want_s)
     hi, hs = sh.search(Q, 20)
-    assert np.array_equal(hi, want_i + 1000)
-
-
-def test_memory_pool_hook_incremental(golden_dir, fake_embedder):
-    """install_memory_pool on a MemoryPool-shaped object: same selection as the reference fixture,
-    and nodes added later are appended to the HBM index (config 4's incremental path)."""
-    import torch
-    from comorag_amd import hooks
-    m = json.load(open(os.path.join(golden_dir, "mempool.json")))
-
-    class Node:
-        def __init__(self, content):
-            self.content, self.embedding = content, None
-
-    class Pool:                                         # attribute names of utils/memory_utils.py:MemoryPool
-        def __init__(self, contents):
-            self.pool = [Node(c) for c in contents]
-            self.embedding_model = fake_embedder
-        def compute_probe_note_embeddings(self, force_recompute=False):
-            todo = [n for n in self.pool if n.embedding is None]
-            if todo:
-                for n, e in zip(todo, fake_embedder.encode([n.content for n in todo])):
-                    n.embedding = e                     # torch tensors, as BGE's encode returns
-    pool = hooks.install_memory_pool(Pool(m["contents"]))
-    sel = pool.retrieve_similar_nodes(m["probe"], top_percent=0.5)
-    assert [pool.pool.index(s) for s in sel] == m["selected"]
-    pool.pool.append(Node(m["probe"]))                  # a fused node identical to the probe text
-    sel2 = pool.retrieve_similar_nodes(m["probe"], top_percent=0.1)
-    assert len(sel2) == 1 and sel2[0] is pool.pool[-1] and len(pool._hip_state["index"]) == len(m["contents"]) + 1
+    assert np.array_equal(hi, want_i + 1000) and np.array_equal(hs, want_s)
+    plain.close()

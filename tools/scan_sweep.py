@@ -43,5 +43,17 @@ for env in variants:
     idx.profile(False)
     p = idx.profile_collect()
     kms = p["total_ms"] / p["launches"]
-    print(f"{env!s:60s} kernel {kms:7.3f} ms  step {dt:7.3f} ms  scan {p['bytes_per_launch']/kms/1e6:7.1f} GB/s  qps {batch/dt*1e3:9.0f}", flush=True)
+    outs = [(torch.empty((batch, k), dtype=torch.int64, device=dev), torch.empty((batch, k), dtype=torch.float32, device=dev)) for _ in range(2)]
+    for i in range(4):
+        h = idx.search_pipelined(q, k, outs[i & 1][0], outs[i & 1][1])
+    idx.sync(h); torch.cuda.synchronize()
+    idx.profile(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        h = idx.search_pipelined(q, k, outs[i & 1][0], outs[i & 1][1])
+    idx.sync(h); torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / steps * 1e3
+    idx.profile(False)
+    p2 = idx.profile_collect(); kms2 = p2["total_ms"] / max(p2["launches"], 1)
+    print(f"{env!s:50s} kernel {kms:7.3f} ms step {dt:7.3f} ms | pipelined: kernel {kms2:7.3f} ms step {dt2:7.3f} ms  qps {batch/dt*1e3:8.0f} / {batch/dt2*1e3:8.0f}", flush=True)
     idx.close()
