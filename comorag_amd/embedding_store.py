@@ -12,6 +12,13 @@ ComoRAG.py / timeline_utils.py / cluster_utils.py run on it unchanged.  What dif
   (MFMA-fragment-major panels in HBM) whose row ids equal `hash_id_to_idx` — the retrieval hooks
   (comorag_amd/hooks.py) search it instead of re-materialising host matrices.
 
+* optional append-only persistence (`persist="sidecar"`, or `global_config.store_format`): the
+  reference rewrites the whole parquet file and rebuilds four dicts on every insert
+  (embedding_store.py:109-120 → O(N) per insert, O(N^2) for the probe loop's incremental appends).
+  Sidecar mode appends to `vdb_{ns}.rows.jsonl` (hash_id, content) + `vdb_{ns}.f32` (raw fp32
+  matrix) and updates the dicts incrementally; `export_parquet()` writes the reference-schema file
+  on demand, and an existing `vdb_{ns}.parquet` is imported on first load.
+
 Conscious deviations: `hash_id_to_text` / `text_to_hash_id` exist on an empty store too (the
 reference leaves them undefined until the first save, embedding_store.py:106-107).
 """
@@ -55,14 +62,20 @@ class _RowList:
 
 
 class EmbeddingStore:
-    def __init__(self, embedding_model, db_filename, batch_size, namespace):
+    def __init__(self, embedding_model, db_filename, batch_size, namespace, persist: Optional[str] = None):
         self.embedding_model = embedding_model
         self.batch_size = batch_size
         self.namespace = namespace
+        cfg = getattr(embedding_model, "global_config", None)
+        self.persist = persist or getattr(cfg, "store_format", None) or "parquet"
+        if self.persist not in ("parquet", "sidecar"):
+            raise ValueError(f"persist must be 'parquet' or 'sidecar', got {self.persist!r}")
         if not os.path.exists(db_filename):
             logger.info(f"Creating working directory: {db_filename}")
             os.makedirs(db_filename, exist_ok=True)
         self.filename = os.path.join(db_filename, f"vdb_{self.namespace}.parquet")
+        self._rows_file = os.path.join(db_filename, f"vdb_{self.namespace}.rows.jsonl")
+        self._mat_file = os.path.join(db_filename, f"vdb_{self.namespace}.f32")
         self._lock = threading.RLock()
         self._mat = np.empty((0, 0), dtype=np.float32)
         self._n = 0
@@ -93,9 +106,54 @@ class EmbeddingStore:
         self.hash_id_to_text = {h: t for h, t in zip(self.hash_ids, self.texts)}
         self.text_to_hash_id = {t: h for h, t in zip(self.hash_ids, self.texts)}
 
+    def _load_sidecar(self) -> bool:
+        import json
+        if not (os.path.exists(self._rows_file) and os.path.exists(self._mat_file)):
+            return False
+        with open(self._rows_file, encoding="utf-8") as f:
+            for line in f:
+                if line.strip():
+                    h, t = json.loads(line)
+                    self.hash_ids.append(h); self.texts.append(t)
+        n = len(self.hash_ids)
+        if n:
+            flat = np.fromfile(self._mat_file, dtype=np.float32)
+            dim = len(flat) // n
+            if dim * n != len(flat):       # torn tail after a crash: keep whole rows only
+                raise IOError(f"{self._mat_file}: {len(flat)} floats is not a multiple of {n} rows")
+            self._reserve(n, dim)
+            self._mat[:n] = flat.reshape(n, dim)
+            self._n = n
+        return True
+
+    def _append_sidecar(self, hash_ids, texts, rows: np.ndarray) -> None:
+        import json
+        with open(self._mat_file, "ab") as f:          # matrix first: a torn write leaves extra floats, never a
+            np.ascontiguousarray(rows, dtype=np.float32).tofile(f)   # row without its vector
+            f.flush(); os.fsync(f.fileno())
+        with open(self._rows_file, "a", encoding="utf-8") as f:
+            for h, t in zip(hash_ids, texts):
+                f.write(json.dumps([h, t], ensure_ascii=False) + "\n")
+            f.flush(); os.fsync(f.fileno())
+
+    def export_parquet(self, path: Optional[str] = None) -> str:
+        """Write the reference-schema parquet (`hash_id`, `content`, `embedding: list<float>`)."""
+        keep = self.filename
+        if path is not None:
+            self.filename = path
+        try:
+            self._write_parquet()
+        finally:
+            out, self.filename = self.filename, keep
+        return out
+
     def _load_data(self):
         """embedding_store.py:92-107.  Reads files written by the reference or by this class."""
         self.hash_ids, self.texts = [], []
+        if self.persist == "sidecar" and self._load_sidecar():
+            self._rebuild_maps()
+            logger.info(f"Loaded {len(self.hash_ids)} records from {self._rows_file}")
+            return
         if os.path.exists(self.filename):
             import pyarrow.parquet as pq
             t = pq.read_table(self.filename, columns=["hash_id", "content", "embedding"])
@@ -113,10 +171,17 @@ class EmbeddingStore:
                 self._n = n
             assert len(self.hash_ids) == len(self.texts) == self._n
             logger.info(f"Loaded {len(self.hash_ids)} records from {self.filename}")
+            if self.persist == "sidecar" and self._n:      # import an existing reference file once
+                self._append_sidecar(self.hash_ids, self.texts, self._mat[:self._n])
         self._rebuild_maps()
 
     def _save_data(self):
         """embedding_store.py:109-120 — same file name and schema, whole-file rewrite."""
+        self._write_parquet()
+        self._rebuild_maps()
+        logger.info(f"Saved {len(self.hash_ids)} records to {self.filename}")
+
+    def _write_parquet(self):
         import pyarrow as pa
         import pyarrow.parquet as pq
         n, dim = self._n, (self._mat.shape[1] if self._n else 0)
@@ -128,8 +193,6 @@ class EmbeddingStore:
         tmp = self.filename + ".tmp"
         pq.write_table(table, tmp)
         os.replace(tmp, self.filename)
-        self._rebuild_maps()
-        logger.info(f"Saved {len(self.hash_ids)} records to {self.filename}")
 
     def _upsert(self, hash_ids, texts, embeddings):
         emb = np.asarray(embeddings)
@@ -146,7 +209,16 @@ class EmbeddingStore:
         if self._index is not None:
             self._index.append(new_rows)
         logger.info("Saving new records.")
-        self._save_data()
+        if self.persist == "sidecar":
+            self._append_sidecar(hash_ids, texts, new_rows)
+            base = self._n - len(hash_ids)
+            for i, (h, t) in enumerate(zip(hash_ids, texts)):      # incremental dict update: O(new rows)
+                self.hash_id_to_idx[h] = base + i
+                self.hash_id_to_row[h] = {"hash_id": h, "content": t}
+                self.hash_id_to_text[h] = t
+                self.text_to_hash_id[t] = h
+        else:
+            self._save_data()
 
     # ------------------------------------------------------------------ reference API
     def get_missing_string_hash_ids(self, texts: List[str]):

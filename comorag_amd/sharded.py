@@ -26,10 +26,11 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 class ShardedIndex:
     def __init__(self, dim: int, dtype: str = "bf16", device: int = 0, rank: int = 0, world: int = 1,
-                 group=None, base: int = 0, capacity_hint: int = 0, index=None):
+                 group=None, base: int = 0, capacity_hint: int = 0, index=None, force_exchange: bool = False):
         self.dim, self.dtype, self.device = dim, dtype, device
         self.rank, self.world, self.group = rank, world, group
         self.base = int(base)          # global id of local row 0
+        self.exchange = world > 1 or force_exchange   # force_exchange: run the RCCL path on a 1-rank group (tests)
         if index is None:
             from .index import DenseIndex
             index = DenseIndex(dim, dtype, device=device, capacity_hint=capacity_hint)
@@ -84,7 +85,7 @@ class ShardedIndex:
                 g_sc=torch.empty((self.world * nq, k), dtype=torch.float32, device=dev),
                 o_ids=None, o_sc=None, done=None)
             b = self._bufs[key]
-            if self.world > 1:
+            if self.exchange:
                 b["o_ids"] = torch.empty((nq, k), dtype=torch.int64, device=dev)
                 b["o_sc"] = torch.empty((nq, k), dtype=torch.float32, device=dev)
             else:
@@ -110,7 +111,7 @@ class ShardedIndex:
         nq = q_t.shape[0]
         b = self._buffers(slot, nq, k, dev)
         handle = self.local.search_pipelined(q_t, k, b["ids"], b["sc"], wait_event=q_ready)
-        if self.world > 1:
+        if self.exchange:
             if self._post is None:
                 self._post = self.local.pipeline_stream(2)
             with torch.cuda.stream(self._post):

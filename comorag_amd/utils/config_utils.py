@@ -26,6 +26,7 @@ class BaseConfig:
     # new, opt-in (reference behaviour by default)
     index_dtype: str = "f32"                      # "f32" | "bf16" | "f16": storage dtype of the HBM index
     device: int = 0
+    store_format: str = "parquet"                 # "parquet" (reference behaviour) | "sidecar" (append-only files)
     embedding_cache_enabled: bool = False         # probed with hasattr by the reference (BGEEmbedding.py:57-61)
     embedding_cache_path: Optional[str] = None
 

@@ -268,3 +268,38 @@ def test_pipelined_search_single_rank():
     hi, hs = sh.search(Q, 20)
     assert np.array_equal(hi, want_i + 1000) and np.array_equal(hs, want_s)
     plain.close()
+
+
+def test_rccl_exchange_path_one_rank(tmp_path):
+    """The N>1 code path (ExternalStream on the pipeline's post stream → RCCL all_gather_into_tensor →
+    cmr_merge_topk_dev) run mechanically on a 1-rank `nccl` group in a subprocess (a single-GPU box
+    cannot host two RCCL ranks).  Numerics of multi-shard merging are covered by the logical-shard
+    and gloo tests."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+        import numpy as np, torch, torch.distributed as dist
+        from oracle import retrieval_np as orc
+        from comorag_amd.index import DenseIndex
+        from comorag_amd.sharded import ShardedIndex
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        X = orc.synthetic_corpus(40_000, 128, seed=1); Q = orc.synthetic_queries(16, 128, seed=2, planted=X)
+        plain = DenseIndex(128, "bf16"); plain.append(X)
+        wi, ws, _, _ = plain.search(Q, 20)
+        sh = ShardedIndex(128, "bf16", rank=0, world=1, base=500, force_exchange=True)
+        sh.local.append(X)
+        q = torch.from_numpy(Q).cuda(); torch.cuda.synchronize()
+        for i in range(6):
+            b = sh.search_pipelined(q, 20, i & 1)
+        b["done"].synchronize()
+        assert np.array_equal(b["o_ids"].cpu().numpy(), wi + 500) and np.array_equal(b["o_sc"].cpu().numpy(), ws)
+        hi, hs = sh.search(Q, 20)
+        assert np.array_equal(hi, wi + 500)
+        dist.destroy_process_group()
+        print("EXCHANGE_OK")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -115,3 +115,33 @@ def test_make_cache_embed_roundtrip(tmp_path):
     assert a[:, 0].tolist() == [2.0, 1.0, 4.0] and b[:, 0].tolist() == [1.0, 2.0, 2.0]
     c = f(prompts=["aa"], instruction="other", max_length=16)          # different instruction → different key
     assert calls[-1] == ["aa"] and c.shape == (1, 3)
+
+
+def test_sidecar_persistence_is_append_only_and_equivalent(tmp_path, fake_embedder):
+    """persist="sidecar": same observable store as parquet mode, files only ever grow, reload and
+    parquet export/import round-trip."""
+    from tests.conftest import FakeEmbedder
+    a = EmbeddingStore(FakeEmbedder(32), str(tmp_path / "p"), 8, "chunk")
+    b = EmbeddingStore(FakeEmbedder(32), str(tmp_path / "s"), 8, "chunk", persist="sidecar")
+    sizes = []
+    for batch in (["x", "y", "x"], ["z", "y", "w"], [], ["w"], ["q" * 50, "naïve ☕"]):
+        ra, rb = a.insert_strings(batch), b.insert_strings(batch)
+        assert repr(ra) == repr(rb)
+        assert a.hash_ids == b.hash_ids and a.texts == b.texts and a.hash_id_to_idx == b.hash_id_to_idx
+        assert a.hash_id_to_row == b.hash_id_to_row and a.text_to_hash_id == b.text_to_hash_id
+        sizes.append((os.path.getsize(b._mat_file) if os.path.exists(b._mat_file) else 0))
+    assert sizes == sorted(sizes) and sizes[-1] == len(b.hash_ids) * 32 * 4
+    assert not os.path.exists(b.filename)                         # no parquet rewrite in sidecar mode
+    b2 = EmbeddingStore(FakeEmbedder(32), str(tmp_path / "s"), 8, "chunk", persist="sidecar")
+    assert b2.hash_ids == a.hash_ids and b2.texts == a.texts
+    np.testing.assert_array_equal(b2.get_embeddings(b2.get_all_ids()), a.get_embeddings(a.get_all_ids()))
+    out = b2.export_parquet()
+    import pandas as pd
+    df = pd.read_parquet(out)                                     # reference reader
+    assert df["hash_id"].tolist() == a.hash_ids and df["content"].tolist() == a.texts
+    # importing an existing reference-schema parquet into sidecar mode
+    c = EmbeddingStore(FakeEmbedder(32), str(tmp_path / "p"), 8, "chunk", persist="sidecar")
+    assert c.hash_ids == a.hash_ids and os.path.exists(c._mat_file)
+    c.insert_strings(["brand new"])
+    c2 = EmbeddingStore(FakeEmbedder(32), str(tmp_path / "p"), 8, "chunk", persist="sidecar")
+    assert c2.hash_ids == a.hash_ids + [compute_mdhash_id("brand new", prefix="chunk-")]
