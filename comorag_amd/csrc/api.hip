@@ -21,7 +21,7 @@
 #define CMR_DT_F32 0
 #define CMR_PANEL_ROWS 32
 #define CMR_SCAN_WAVES 8
-#define CMR_CORPUS_SLACK (32 * 1024)
+#define CMR_CORPUS_SLACK (128 * 1024)
 
 bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring);  // ring_audit.cpp (generated at build)
 
@@ -115,6 +115,7 @@ struct cmr_index {
     int force_asm = -1;      // CMR_SCAN_ASM_RING=0|1
     int force_grid = 0;      // CMR_SCAN_GRID
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
+    int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     int reserve_cus = 96;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves to the next pass's pre-phase (160 CUs still saturate HBM)
     std::mutex pipe_mu;
@@ -235,7 +236,7 @@ int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, in
 // event orders them, so the pre-phase of the NEXT pass/batch can overlap this pass's main scan.
 int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, hipStream_t sq, hipEvent_t ev_pre, hipEvent_t ev_scan,
                  const float* q_dev, int nqp,
-                 int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev) {
+                 int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false) {
     CmrScanGeom g;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
     if (!ws->flag.p) {   // zeroed once; check_query_flag() re-arms it after reporting
@@ -244,9 +245,20 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     }
     int rc = make_geom(idx, nqp, k, true, &g);
     if (rc) return rc;
-    if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
-    const int NQ = g.nqt * 32;
-    const int W = g.grid * CMR_SCAN_WAVES;
+    int NQ, W, tiles;
+    if (wide) {
+        // register-resident queries: 32 per wave, 8 or 4 waves per workgroup, one list row per
+        // (workgroup, query); one workgroup per CU
+        const int nqb = cmr_wide_queries(idx->dtype, idx->dpad);
+        g.nqt = 1;
+        g.grid = (int)std::max<long long>(1, std::min<long long>(npanels, idx->n_cu));
+        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        NQ = nqb; W = g.grid; tiles = nqb / 32;
+    } else {
+        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        NQ = g.nqt * 32; W = g.grid * CMR_SCAN_WAVES; tiles = g.nqt;
+    }
+    const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
     // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
     // best of that sample per query as the threshold of the next level / of the main scan.  Any
     // subset's k-th best is a valid lower bound of the global k-th best, so results are unchanged;
@@ -264,10 +276,10 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         }
     }
     const long long max_sample = std::max(level_panels[0], level_panels[1]);
-    const int Ws = max_sample ? (int)((max_sample + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES : 0;
+    const int Ws = max_sample ? (int)((max_sample + lists_per_wg - 1) / lists_per_wg) * lists_per_wg : 0;
     // sample passes and the main pass use separate list buffers: in pipelined mode the next batch's
     // sampling runs while this batch's main scan still owns `lists`
-    HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
+    HIP_TRY(ws->qfrag.ensure((size_t)tiles * g.ks * 1024));
     HIP_TRY(ws->lists.ensure((size_t)W * NQ * g.cap * 8));
     HIP_TRY(ws->cnt.ensure((size_t)W * NQ * 4));
     HIP_TRY(ws->mm.ensure((size_t)W * NQ * 8));
@@ -277,20 +289,20 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(ws->s_mm.ensure((size_t)Ws * NQ * 8));
     }
     HIP_TRY(ws->tau.ensure((size_t)2 * NQ * 8));
-    HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p, (int*)ws->flag.p, sp));
+    HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev, nqp, idx->dim, idx->dpad, tiles, ws->qfrag.p, (int*)ws->flag.p, sp));
     CmrScanArgs a{};
     a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
     a.nq = nqp;
     for (int lv = 0; lv < n_levels; ++lv) {
         const long long spn = level_panels[lv];
-        const int Wl = (int)((spn + CMR_SCAN_WAVES - 1) / CMR_SCAN_WAVES) * CMR_SCAN_WAVES;
+        const int Wl = (int)((spn + lists_per_wg - 1) / lists_per_wg) * lists_per_wg;
         CmrScanGeom gs = g;
-        gs.grid = Wl / CMR_SCAN_WAVES;
+        gs.grid = Wl / lists_per_wg;
         CmrScanArgs as = a;
         as.lists = (u64*)ws->s_lists.p; as.cnt = (int*)ws->s_cnt.p; as.mm = (float2*)ws->s_mm.p;
         as.sample_waves = (int)spn; as.sample_stride = (int)(npanels / spn);
         u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
-        HIP_TRY(cmr_launch_scan_topk(gs, as, sp));
+        HIP_TRY(wide ? cmr_launch_scan_wide(gs, as, sp) : cmr_launch_scan_topk(gs, as, sp));
         HIP_TRY(cmr_launch_merge_query((const u64*)ws->s_lists.p, (const int*)ws->s_cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
                                        nullptr, nullptr, nullptr, tau_out, sp));
         a.tau_init = tau_out;
@@ -311,7 +323,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(hipEventCreate(&pe.b));
         HIP_TRY(hipEventRecord(pe.a, sm));
     }
-    HIP_TRY(cmr_launch_scan_topk(g, a, sm));
+    HIP_TRY(wide ? cmr_launch_scan_wide(g, a, sm) : cmr_launch_scan_topk(g, a, sm));
     if (prof) {
         HIP_TRY(hipEventRecord(pe.b, sm));
         std::lock_guard<std::mutex> pg(idx->prof_mu);
@@ -331,13 +343,17 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
                    float* min_dev, float* max_dev) {
     if (k > CMR_MAX_K) return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
-    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
-    for (int q0 = 0; q0 < nq; q0 += per_pass) {
-        const int nqp = std::min(per_pass, nq - q0);
+    const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
+    const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
+    for (int q0 = 0; q0 < nq;) {
+        const int left = nq - q0;
+        const bool wide = wideq > 0 && left > narrow;          // more than one narrow pass left: go wide
+        const int nqp = std::min(wide ? wideq : narrow, left);
         int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr);
+                              max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
+        q0 += nqp;
     }
     return CMR_OK;
 }
@@ -363,19 +379,25 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
     if (wait_event) HIP_TRY(hipStreamWaitEvent(P.sp, wait_event, 0));
     if (k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "pipelined search supports k <= %d", CMR_MAX_K);
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
-    const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
+    const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
+    const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
     PipeSlot* last = nullptr;
-    for (int q0 = 0; q0 < nq; q0 += per_pass) {
-        const int nqp = std::min(per_pass, nq - q0);
+    for (int q0 = 0; q0 < nq;) {
+        const int left = nq - q0;
+        const bool wide = wideq > 0 && left > narrow;
+        const int nqp = std::min(wide ? wideq : narrow, left);
         PipeSlot* sl = &P.slot[P.next++ & 1];
         if (sl->used) HIP_TRY(hipStreamWaitEvent(P.sp, sl->main_done, 0));   // its buffers are free again
-        int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, q_dev + (size_t)q0 * idx->dim, nqp, k, idx->reserve_cus,
+        // the wide kernel is MFMA-bound, not HBM-bound: it keeps every CU
+        int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, q_dev + (size_t)q0 * idx->dim, nqp, k,
+                              wide ? 0 : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr);
+                              max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(sl->main_done, P.sq));
         sl->used = true;
         last = sl;
+        q0 += nqp;
     }
     if (done_event) *done_event = last ? last->main_done : nullptr;
     return CMR_OK;
@@ -505,6 +527,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_asm = env_int("CMR_SCAN_ASM_RING", -1);
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
+    idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", 96);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;

@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned v4u;  // native 128-bit vec
 #define CMR_PANEL_ROWS 32   // rows per panel == MFMA M (32x32 tiles)
 #define CMR_SCAN_THREADS 512
 #define CMR_SCAN_WAVES 8
-#define CMR_CORPUS_SLACK (32 * 1024)  // bytes readable past the last panel (ring over-read)
+#define CMR_CORPUS_SLACK (128 * 1024)  // bytes readable past the last panel (load rings over-read up to 88 KiB)
 
 __device__ __forceinline__ u64 cmr_make_key(float v, unsigned row) {
     unsigned u = __float_as_uint(v + 0.0f);

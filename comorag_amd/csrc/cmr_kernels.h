@@ -45,6 +45,10 @@ struct CmrScanArgs {
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
 hipError_t cmr_launch_scan_scores(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
+// wide-batch (register-resident queries) top-k scan: 32 queries per wave, 8 (768-d) or 4 (1024-d) waves
+hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
+int cmr_wide_queries(int dtype, int dpad);      // queries per pass of the wide kernel (0 = unavailable)
+size_t cmr_wide_lds_bytes(int ks, int cap);
 
 // queries fp32 [nq, dim] (device) -> fragment-ordered blocks of the index dtype, zero padded
 hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt,

@@ -22,6 +22,8 @@
 //    take the slow path: push (score,row) keys into the (wave,query) list in global scratch and,
 //    when a list is nearly full, compact it to its k best (rank by counting) and raise tau.
 //    Expected pushes per query per wave are k*ln(rows/k): the slow path is rare by construction.
+#include <cstdlib>
+
 #include "cmr_device.h"
 #include "cmr_kernels.h"
 
@@ -46,11 +48,12 @@ struct ScanP {
     const u64* tau_init;   // per-query initial threshold keys (from the sampling pass) or nullptr
 };
 
+// Slow path, part 1 (inline, a handful of registers, no waits on global memory): push the keys of
+// one 32x32 score tile that beat the lane's threshold into the (wave, query) lists.  Returns the
+// mask of this tile's queries whose list is nearly full.
 template <int CAP>
-__device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0, long long nrows, int k,
-                                               u64& tau_key, float& tau_f, int* cnt_t, u64* list_t,
-                                               u64* stage, int lane) {
-    constexpr int EPL = CAP / 64;
+__device__ __forceinline__ u64 topk_push(const f32x16& acc, long long row0, long long nrows, u64 tau_key, int* cnt_t,
+                                         u64* list_t, int lane) {
     const int ql = lane & 31;
     const unsigned hrow = 4u * (unsigned)(lane >> 5);
 #pragma unroll
@@ -63,9 +66,22 @@ __device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0
             list_t[(size_t)ql * CAP + slot] = key;
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // pushes landed (same-CU L1 is coherent)
+    // LDS ops of one wave complete in order, so the counters are current without any fence.  The
+    // pushed keys themselves are only read back by a compaction, which fences (s_waitcnt vmcnt(0))
+    // itself — a fence on every slow-path entry would drain the load ring / DMA ring each time.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int c = __hip_atomic_load(&cnt_t[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    u64 need = __ballot(c > CAP - 32) & 0xFFFFFFFFull;
+    return __ballot(c > CAP - 32) & 0xFFFFFFFFull;
+}
+
+// Slow path, part 2 (rare): compact every list in `need` to its k best keys (rank by counting; keys
+// are unique so ranks are a permutation) and raise the owning lanes' thresholds.
+template <int CAP>
+__device__ __forceinline__ void topk_compact(u64 need, int k, u64& tau_key, float& tau_f, int* cnt_t, u64* list_t, u64* stage,
+                                             int lane) {
+    constexpr int EPL = CAP / 64;
+    const int ql = lane & 31;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // pushes landed (same-CU L1 is coherent)
     while (need) {
         const int j = __ffsll((long long)need) - 1;
         need &= need - 1;
@@ -87,7 +103,6 @@ __device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0
 #pragma unroll
             for (int i = 0; i < EPL; ++i) rk[i] += (kj > e[i]) ? 1 : 0;
         }
-        // keys are unique => ranks are a permutation of 0..n-1; keep the k best, in order
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
             const int idx = lane + 64 * i;
@@ -102,6 +117,24 @@ __device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
+}
+
+template <int CAP>
+__device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0, long long nrows, int k,
+                                               u64& tau_key, float& tau_f, int* cnt_t, u64* list_t,
+                                               u64* stage, int lane) {
+    const u64 need = topk_push<CAP>(acc, row0, nrows, tau_key, cnt_t, list_t, lane);
+    if (need) topk_compact<CAP>(need, k, tau_key, tau_f, cnt_t, list_t, stage, lane);
+}
+
+// Out-of-line compaction for the wide kernel: its resident query registers must not be squeezed by
+// the compaction's temporaries, and a call's callee-saved spill/reload (with its s_waitcnt vmcnt(0),
+// which drains the DMA ring) must stay off the common slow path — so only the rare compaction is a
+// call; the pushes are inline.
+template <int CAP>
+__device__ __attribute__((noinline)) void topk_compact_call(u64 need, int k, u64* tau_key, float* tau_f, int* cnt_t, u64* list_t,
+                                                            u64* stage, int lane) {
+    topk_compact<CAP>(need, k, *tau_key, *tau_f, cnt_t, list_t, stage, lane);
 }
 
 template <int DT, int NQT, int CAP, int R, int MODE, int ASMRING>
@@ -351,6 +384,250 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.scores = a.scores; p.ld = a.ld; p.nq = a.nq;
     p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.tau_init = a.tau_init;
     return p;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wide-batch scan: up to 256 queries in ONE pass over the corpus (BASELINE config 3's batch-256).
+// The LDS-resident query tile of scan_kernel tops out at 64 queries (96 KiB); here the queries
+// live in REGISTERS: every wave keeps the MFMA B-operands of ITS 32 queries resident (KS blocks x
+// 4 VGPRs = 192 registers at 768-d), a workgroup of WAVES waves covers WAVES*32 queries (8 waves,
+// two per SIMD, 256 queries at 768-d; 4 waves, 128 queries at 1024-d where a tile needs 256
+// registers).  All waves consume the same corpus blocks: the stream goes HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: one wave moves one 1-KiB block, lane-linear — exactly the block layout)
+// into a ring of NST groups of 8 blocks, NST-1 groups (88 KiB) in flight per workgroup and no VGPR
+// spent on it; every wave reads each block back (ds_read_b128, one block ahead) and issues one
+// MFMA per block.  HBM traffic stays 1x while the MFMA work is 4x that of the 64-query kernel
+// (75 % of the MFMA pipe at the HBM rate for 768-d bf16: still HBM-bound on paper).
+//   per group g:  first ds_reads of group g        (validated by the previous iteration's barrier)
+//                 s_waitcnt vmcnt(PPG*(NST-3))   my DMA pieces of group g+1 have landed
+//                 s_barrier                        everybody's have; everybody left group g-1
+//                 DMA group g+NST-1 -> stage (g-1) mod NST
+//                 8 x (MFMA + ds_read_b128 three blocks ahead) from stage g mod NST
+// Counted waits + raw s_barrier (__syncthreads() would drain the DMA queue, guide §5); the DMAs are
+// inline asm (§5.7 recipe: M0 = LDS destination, saved/restored inside the statement) so hipcc
+// neither counts them nor drains them before LDS reads.  The tail over-reads NST-1 groups past the
+// range: CMR_CORPUS_SLACK covers it.  The top-k epilogue, candidate lists and thresholds are the
+// per-wave ones of scan_kernel; list / counter rows are laid out [workgroup][WAVES*32 queries] so
+// merge_query_kernel consumes them with W = gridDim.x.
+#define WIDE_GROUP 8      // blocks per staged group
+#define WIDE_STAGES 12    // LDS ring depth in groups (96 KiB)
+
+template <int DT, int KS, int WAVES, int CAP, int ABL = 0>   // ABL: developer ablation (1 no MFMA, 2 no DMA, 3 no barrier)
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP P) {
+    static_assert(KS % WIDE_GROUP == 0 && WIDE_GROUP % WAVES == 0, "group/wave geometry");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NQB = WAVES * 32;               // queries per workgroup pass
+    constexpr int GPP = KS / WIDE_GROUP;          // groups per panel
+    constexpr int NST = WIDE_STAGES;
+    constexpr int PPG = WIDE_GROUP / WAVES;       // DMA pieces per wave per group
+    // With two waves per SIMD a wave owns 256 registers: 48 resident fragments (192) + accumulator,
+    // read-ahead blocks and epilogue state overflow by a few registers, and hipcc's spill reloads
+    // (scratch_load + s_waitcnt vmcnt(0) at the top of every panel) drain the DMA ring — measured
+    // 1.3 of 4.7 ms.  The last KLDS k-steps of the tile are therefore served from LDS.
+    constexpr int KLDS = WAVES == 8 ? 4 : 0;
+    constexpr int KREG = KS - KLDS;
+
+    v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][WIDE_GROUP][64]
+    int* cnt_all = reinterpret_cast<int*>(smem + NST * WIDE_GROUP * 1024);            // [WAVES][32]
+    u64* cstage_all = reinterpret_cast<u64*>(cnt_all + WAVES * 32);                   // [WAVES][CAP+2]
+    v4u* qlds = reinterpret_cast<v4u*>(cstage_all + WAVES * (CAP + 2)) + (size_t)wave * KLDS * 64 + lane;   // [WAVES][KLDS][64]
+    int* cnt_w = cnt_all + wave * 32;
+    u64* cstage = cstage_all + wave * (CAP + 2);
+    for (int i = tid; i < WAVES * 32; i += WAVES * 64) cnt_all[i] = 0;
+
+    // this wave's query fragments -> registers (static indices everywhere below)
+    v4u qreg[KREG];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const v4u v = P.qfrag[((size_t)wave * KS + ks) * 64 + lane];
+        if (ks < KREG) qreg[ks < KREG ? ks : 0] = v;
+        else qlds[(ks - KREG) * 64] = v;                 // written and read by the same lane only
+    }
+    // Make hipcc retire every query-fragment load HERE: left alone it defers each wait to the
+    // fragment's first use inside the panel loop, where stale low-count s_waitcnt vmcnt(N) would
+    // drain the hand-counted DMA ring on every iteration.
+#pragma unroll
+    for (int ks = 0; ks < KREG; ++ks) asm volatile("" ::"v"(qreg[ks]));
+
+    const int nb = gridDim.x;
+    int p0, p1;
+    if (P.sample_waves > 0) {   // sampling pass: workgroup b scans the single strided panel b*stride
+        p0 = blockIdx.x * P.sample_stride;
+        p1 = (int)blockIdx.x < P.sample_waves ? p0 + 1 : p0;
+    } else {
+        p0 = (int)(((long long)blockIdx.x * P.npanels) / nb);
+        p1 = (int)(((long long)(blockIdx.x + 1) * P.npanels) / nb);
+    }
+
+    float rmin = __builtin_inff(), rmax = -__builtin_inff(), tau_f = -__builtin_inff();
+    u64 tau_key = 0ull;
+    {
+        const int q = wave * 32 + (lane & 31);
+        if (q >= P.nq) {
+            tau_key = ~0ull;
+            tau_f = __builtin_inff();
+        } else if (P.tau_init) {
+            tau_key = P.tau_init[q];
+            if (tau_key) tau_f = cmr_key_score(tau_key);
+        }
+    }
+    u64* list_w = P.lists + ((size_t)blockIdx.x * NQB + (size_t)wave * 32) * CAP;
+    __syncthreads();
+
+    if (p1 > p0) {
+        const char* gsrc = reinterpret_cast<const char*>(P.corpus + (size_t)p0 * KS * 64) + (size_t)wave * 1024 + (size_t)lane * 16;
+        const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u;
+        auto dma_group = [&](const char* g_src, int stage) {
+            const unsigned dst = lds_base + (unsigned)stage * (WIDE_GROUP * 1024u);   // wave-uniform LDS byte address
+            unsigned keep;
+            if constexpr (PPG == 1) {
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g_src), "s"(dst) : "memory");
+            } else {
+                const char* g_src2 = g_src + 4096;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                             "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g_src), "v"(g_src2), "s"(dst) : "memory");
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < NST - 1; ++d) dma_group(gsrc + (size_t)d * WIDE_GROUP * 1024, d);
+        gsrc += (size_t)(NST - 1) * WIDE_GROUP * 1024;
+        int st = 0;                                   // stage holding the current group
+        // group 0 must be complete before the first reads; from then on the barrier of iteration g
+        // validates group g+1, so the reads of group g are issued BEFORE that barrier and the MFMA
+        // chain never drains at a barrier (measured: ~600 of 1100 cycles per group were that bubble)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 2)) : "memory");
+
+        for (int p = p0; p < p1; ++p) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+            for (int g = 0; g < GPP; ++g) {
+                const v4u* buf = stage_lds + (size_t)st * WIDE_GROUP * 64 + lane;
+                constexpr int ADEPTH = WAVES == 8 ? 3 : 4;
+                v4u a[ADEPTH];
+#pragma unroll
+                for (int u = 0; u < ADEPTH; ++u) a[u] = buf[u * 64];
+                if constexpr (ABL == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPG * (NST - 3)) : "memory");
+                else if constexpr (ABL == 2 || ABL == 5) asm volatile("s_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
+                if constexpr (ABL != 2 && ABL != 5) dma_group(gsrc + (size_t)g * WIDE_GROUP * 1024, st == 0 ? NST - 1 : st - 1);
+#pragma unroll
+                for (int u = 0; u < WIDE_GROUP; ++u) {
+                    const v4u a_use = a[u % ADEPTH];
+                    __builtin_amdgcn_sched_barrier(0);
+                    constexpr int dummy3 = 0; (void)dummy3;
+                    const int ks = g * WIDE_GROUP + u;
+                    const v4u b = ks < KREG ? qreg[ks < KREG ? ks : 0] : qlds[(ks < KREG ? 0 : ks - KREG) * 64];
+                    if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(a_use), "v"(b));
+                    else acc = CmrBlk<DT>::mma(a_use, b, acc);
+                    if (u + ADEPTH < WIDE_GROUP) a[u % ADEPTH] = buf[(u + ADEPTH) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                st = st + 1 == NST ? 0 : st + 1;
+            }
+            gsrc += (size_t)KS * 1024;
+
+            if constexpr (ABL >= 4) {   // ablation: keep acc alive, skip the epilogue
+                asm volatile("" ::"v"(acc));
+                continue;
+            }
+            const long long row0 = (long long)p * CMR_PANEL_ROWS;
+            const bool partial = row0 + CMR_PANEL_ROWS > P.nrows;
+            float mx, mn;
+            if (!partial) {
+                mx = acc[0]; mn = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) { mx = fmaxf(mx, acc[r]); mn = fminf(mn, acc[r]); }
+            } else {
+                mx = -__builtin_inff(); mn = __builtin_inff();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = row0 + cmr_acc_row(r, lane) < P.nrows;
+                    mx = fmaxf(mx, ok ? acc[r] : -__builtin_inff());
+                    mn = fminf(mn, ok ? acc[r] : __builtin_inff());
+                }
+            }
+            rmax = fmaxf(rmax, mx);
+            rmin = fminf(rmin, mn);
+            if (__any(mx >= tau_f)) {
+                const u64 need = topk_push<CAP>(acc, row0, P.nrows, tau_key, cnt_w, list_w, lane);
+                if (need) {
+                    // address-taken copies live only inside this branch (passing &tau_f itself would pin
+                    // it to scratch and its reload's s_waitcnt vmcnt(0) would drain the DMA ring on
+                    // every panel)
+                    u64 tk = tau_key;
+                    float tf = tau_f;
+                    topk_compact_call<CAP>(need, P.k, &tk, &tf, cnt_w, list_w, cstage, lane);
+                    tau_key = tk;
+                    tau_f = tf;
+                    // retire the scratch reloads of tk / tf HERE: otherwise hipcc waits for them at their
+                    // next use — an unconditional s_waitcnt vmcnt(0) in front of every panel's threshold
+                    // compare, which drains the DMA ring each time
+                    asm volatile("" : "+v"(tau_key), "+v"(tau_f));
+                }
+            }
+        }
+    }
+
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    {
+        const float mn = fminf(rmin, __shfl_xor(rmin, 32));
+        const float mx = fmaxf(rmax, __shfl_xor(rmax, 32));
+        if (lane < 32) {
+            const int q = wave * 32 + lane;
+            P.mm[(size_t)blockIdx.x * NQB + q] = make_float2(mn, mx);
+            P.cnt[(size_t)blockIdx.x * NQB + q] = __hip_atomic_load(&cnt_w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+static int wide_waves(int ks) { return ks == 48 ? 8 : 4; }
+
+size_t cmr_wide_lds_bytes(int ks, int cap) {
+    const int waves = wide_waves(ks);
+    const int klds = waves == 8 ? 4 : 0;
+    return (size_t)WIDE_STAGES * WIDE_GROUP * 1024 + (size_t)waves * 32 * 4 + (size_t)waves * (cap + 2) * 8 +
+           (size_t)waves * klds * 1024;
+}
+
+// wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 8 waves x 32 = 256 queries per pass),
+// ks = 64 (1024-d: a tile needs 256 registers -> 4 waves x 32 = 128 queries per pass)
+int cmr_wide_queries(int dtype, int dpad) {
+    if (dtype == CMR_DT_F32) return 0;
+    if (dpad == 768) return 256;
+    if (dpad == 1024) return 128;
+    return 0;
+}
+
+hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
+    const ScanP p = to_p(g, a);
+    const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap);
+    auto launch = [&](auto kern, int threads) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds, s, p);
+        return hipGetLastError();
+    };
+    const int abl = getenv("CMR_WIDE_ABL") ? atoi(getenv("CMR_WIDE_ABL")) : 0;
+    if (abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128) {
+        if (abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 1>, 512);
+        if (abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 2>, 512);
+        if (abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 3>, 512);
+        if (abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 4>, 512);
+        if (abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 5>, 512);
+        if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 6>, 512);
+    }
+#define WCASE(DT, KSV, WV, CAPV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV) return launch(scan_wide_kernel<DT, KSV, WV, CAPV>, WV * 64);
+    WCASE(CMR_DT_BF16, 48, 8, 128) WCASE(CMR_DT_BF16, 48, 8, 256) WCASE(CMR_DT_F16, 48, 8, 128) WCASE(CMR_DT_F16, 48, 8, 256)
+    WCASE(CMR_DT_BF16, 64, 4, 128) WCASE(CMR_DT_BF16, 64, 4, 256) WCASE(CMR_DT_F16, 64, 4, 128) WCASE(CMR_DT_F16, 64, 4, 256)
+#undef WCASE
+    return hipErrorInvalidValue;
 }
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {

@@ -72,6 +72,23 @@ def test_batch_sizes(nq):
         _check("f32", X, Q, 20)
 
 
+@pytest.mark.parametrize("dtype,d,nq", [("bf16", 768, 65), ("bf16", 768, 256), ("bf16", 768, 300), ("f16", 768, 200),
+                                         ("bf16", 1024, 128), ("f16", 1024, 97), ("bf16", 700, 130)])
+def test_wide_batch_register_resident_queries(dtype, d, nq):
+    """nq > 64 at 768-d / 1024-d: one pass of the wide kernel (queries in registers) per 256 / 128
+    queries; must equal the oracle and, bit for bit, the multi-pass narrow kernel."""
+    X, Q = _mk(40_000 + 17, d, nq, seed=d + nq)
+    X[30_000] = X[11]; Q[3] = X[11]
+    a_ids, a_sc = _check(dtype, X, Q, 20)
+    b_ids, b_sc = _check(dtype, X, Q, 20, env={"CMR_SCAN_NO_WIDE": "1"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+
+
+def test_wide_batch_large_k_and_sampling():
+    X, Q = _mk(300_000, 768, 256, seed=5)          # large enough for both sampling levels
+    _check("bf16", X, Q, 100)
+
+
 @pytest.mark.parametrize("k", [1, 5, 20, 32, 33, 100, 128])
 def test_k_values(k):
     X, Q = _mk(4000, 128, 7, seed=k)

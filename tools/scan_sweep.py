@@ -17,12 +17,12 @@ def gen():
     for b in range(0, rows, 250_000):
         x = torch.randn((min(250_000, rows - b), dim), generator=g, device=dev)
         yield (x / x.norm(dim=1, keepdim=True)).contiguous()
-variants = [dict(), dict(CMR_SCAN_RING="8"), dict(CMR_SCAN_ASM_RING="0"), dict(CMR_SCAN_ASM_RING="0", CMR_SCAN_RING="8"),
+variants = [dict(), dict(CMR_SCAN_NO_WIDE="1"), dict(CMR_SCAN_RING="8"), dict(CMR_SCAN_ASM_RING="0"), dict(CMR_SCAN_ASM_RING="0", CMR_SCAN_RING="8"),
             dict(CMR_SCAN_NO_SAMPLE="1"), dict(CMR_SCAN_GRID="128"), dict(CMR_SCAN_GRID="512")]
 if len(sys.argv) > 3:
     variants = [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[3:]]
 for env in variants:
-    for kk in ("CMR_SCAN_RING", "CMR_SCAN_ASM_RING", "CMR_SCAN_NO_SAMPLE", "CMR_SCAN_GRID"):
+    for kk in ("CMR_SCAN_RING", "CMR_SCAN_ASM_RING", "CMR_SCAN_NO_SAMPLE", "CMR_SCAN_GRID", "CMR_SCAN_NO_WIDE", "CMR_PIPE_RESERVE_CUS", "CMR_WIDE_ABL"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     idx = DenseIndex(dim, "bf16", capacity_hint=rows)
