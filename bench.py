@@ -202,6 +202,21 @@ def main():
                      "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"],
                      "rows_per_gpu": len(sh)},
     }
+    wide_extra = None
+    if rank == 0 and world == 1 and not args.no_extra and args.batch < 256:
+        # BASELINE config 3's batch size on this GPU's shard: 256 queries per step in ONE corpus pass
+        # (wide kernel: queries resident in registers); MFMA-bound rather than HBM-bound
+        g2 = torch.Generator(device=device); g2.manual_seed(8765)
+        q256 = torch.randn((256, args.dim), generator=g2, device=device, dtype=torch.float32)
+        q256 = (q256 / q256.norm(dim=1, keepdim=True)).contiguous()
+        torch.cuda.synchronize(device)
+        steps_w = max(10, args.steps // 2)
+        dtw, profw = run_steps(torch, dist, sh, q256, args.k, steps_w, 3, 1, device)
+        msw = profw["total_ms"] / max(profw["launches"], 1)
+        wide_extra = {"value": 256 * steps_w / dtw, "unit": "queries/s", "batch": 256, "ms_per_step": dtw / steps_w * 1e3,
+                      "kernel_ms": msw, "kernel": "scan_wide_kernel (register-resident queries, LDS-DMA corpus ring)",
+                      "hbm_GBps": profw["bytes_per_launch"] / (msw * 1e-3) / 1e9 if msw else 0.0,
+                      "mfma_TFLOPs": 2.0 * 256 * len(sh) * args.dim / (msw * 1e-3) / 1e12 if msw else 0.0}
     prof_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
     if os.path.exists(prof_file):
         pj = json.load(open(prof_file))
@@ -236,6 +251,8 @@ def main():
             extra["corpus_embed_bf16"] = encode_rate(torch, device, "base", 256, "bf16")
         except Exception as e:  # the headline line must still print
             extra["corpus_embed"] = {"error": repr(e)[:300]}
+        if wide_extra is not None:
+            extra["batch256_one_pass"] = wide_extra
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)
