@@ -75,6 +75,20 @@ def lib() -> C.CDLL:
     with _lock:
         if _lib is not None:
             return _lib
+        if not os.path.exists(LIB_PATH) and "COMORAG_HIP_LIB" not in os.environ:
+            # a fresh checkout (the .so is git-ignored): build it once, under a file lock so that the
+            # ranks of a multi-process launch do not race.  This is a BUILD, not a fallback.
+            try:
+                from filelock import FileLock
+                from . import build as _build
+                os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+                with FileLock(LIB_PATH + ".lock"):
+                    if not os.path.exists(LIB_PATH):
+                        _build.build(force=False, verbose=False)
+            except Exception as e:  # hipcc missing etc.
+                raise ImportError(f"{LIB_PATH} not found and could not be built ({e}). Build it with "
+                                  "`python -m comorag_amd.build` (hipcc --offload-arch=gfx950). "
+                                  "comorag_amd has no CPU fallback.") from e
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found. Build it with `python -m comorag_amd.build` "

@@ -72,11 +72,11 @@ struct DevBuf {
 struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf qfrag, lists, cnt, mm, part, flag, tau, s_lists, s_cnt, s_mm;
+    DevBuf qfrag, lists, cnt, mm, flag, tau, s_lists, s_cnt, s_mm;
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
     void release() {
-        qfrag.release(); lists.release(); cnt.release(); mm.release(); part.release(); flag.release(); tau.release();
+        qfrag.release(); lists.release(); cnt.release(); mm.release(); flag.release(); tau.release();
         s_lists.release(); s_cnt.release(); s_mm.release();
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
         if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -136,6 +136,12 @@ int set_device(int device) {
 }
 
 int check_device(int device_id) {
+    static std::mutex mu;
+    static std::vector<char> ok;                  // devices already validated (hipGetDeviceProperties is slow)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (device_id >= 0 && (size_t)device_id < ok.size() && ok[device_id]) return CMR_OK;
+    }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(CMR_ERR_NO_DEVICE, "no HIP device visible (%s); libcomorag_hip has no CPU fallback",
@@ -145,6 +151,11 @@ int check_device(int device_id) {
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(CMR_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (ok.size() <= (size_t)device_id) ok.resize((size_t)device_id + 1, 0);
+        ok[device_id] = 1;
+    }
     return CMR_OK;
 }
 

@@ -7,10 +7,8 @@
 // ------------------------------------------------------------------------------------------
 // Pack element value by dtype.
 template <int DT> struct Pack;
-template <> struct Pack<CMR_DT_BF16> { static __device__ __forceinline__ unsigned short cvt(float f) { return cmr_f2bf(f); }
-                                       static __device__ __forceinline__ float back(unsigned short h) { return cmr_bf2f(h); } };
-template <> struct Pack<CMR_DT_F16>  { static __device__ __forceinline__ unsigned short cvt(float f) { return cmr_f2h(f); }
-                                       static __device__ __forceinline__ float back(unsigned short h) { return cmr_h2f(h); } };
+template <> struct Pack<CMR_DT_BF16> { static __device__ __forceinline__ unsigned short cvt(float f) { return cmr_f2bf(f); } };
+template <> struct Pack<CMR_DT_F16>  { static __device__ __forceinline__ unsigned short cvt(float f) { return cmr_f2h(f); } };
 
 __device__ __forceinline__ bool cmr_finite(float f) { return (__float_as_uint(f) & 0x7F800000u) != 0x7F800000u; }
 
@@ -131,32 +129,6 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 // Every thread holds up to MERGE_PER_THREAD (+1 carried) keys of the current chunk in registers.
 #define MERGE_PER_THREAD 16
 #define MERGE_POOL (MERGE_THREADS * MERGE_PER_THREAD)
-
-// max of a u64 over the 64 lanes, uniform result.  DPP butterflies inside each row of 16 lanes
-// (quad_perm xor1, xor2, row_half_mirror, row_mirror), then 4 readlanes — no LDS traffic.
-__device__ __forceinline__ u64 cmr_wave_max_u64(u64 v) {
-#define CMR_DPP_MAX(ctrl)                                                                                 \
-    {                                                                                                     \
-        const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), ctrl, 0xF, 0xF, true); \
-        const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, ctrl, 0xF, 0xF, true); \
-        const u64 o = ((u64)ohi << 32) | olo;                                                             \
-        v = o > v ? o : v;                                                                                \
-    }
-    CMR_DPP_MAX(0xB1)    // quad_perm:[1,0,3,2]
-    CMR_DPP_MAX(0x4E)    // quad_perm:[2,3,0,1]
-    CMR_DPP_MAX(0x141)   // row_half_mirror
-    CMR_DPP_MAX(0x140)   // row_mirror
-#undef CMR_DPP_MAX
-    u64 r = 0;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(v >> 32), row * 16);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, row * 16);
-        const u64 x = ((u64)hi << 32) | lo;
-        r = x > r ? x : r;
-    }
-    return r;
-}
 
 // Radix select of the k largest keys held in the block's registers (MERGE_PER_THREAD+1 per
 // thread, 0 = empty): 8 passes over the key bytes, most significant first.  Each pass histograms

@@ -521,7 +521,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
                 for (int u = 0; u < WIDE_GROUP; ++u) {
                     const v4u a_use = a[u % ADEPTH];
                     __builtin_amdgcn_sched_barrier(0);
-                    constexpr int dummy3 = 0; (void)dummy3;
                     const int ks = g * WIDE_GROUP + u;
                     const v4u b = ks < KREG ? qreg[ks < KREG ? ks : 0] : qlds[(ks < KREG ? 0 : ks - KREG) * 64];
                     if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(a_use), "v"(b));
