@@ -242,6 +242,19 @@ def main():
         extra["host_buffer_api"] = host_api_rate(torch, sh2, Qh, args.k)
         extra["host_buffer_api"]["note"] = f"PCIe-inclusive: {rows2} rows, H2D queries + D2H results + sync per call"
         gpu_ids = sh2.local.search(Qh, args.k)[0]
+        try:        # complete ranking of one query (dense_passage_retrieval's all-N return): scan + device radix sort + D2H
+            sh2.local.sorted_scores(Qh[:1])
+            t0 = time.perf_counter()
+            for i in range(10):
+                sh2.local.sorted_scores(Qh[i % len(Qh):i % len(Qh) + 1])
+            dtr = (time.perf_counter() - t0) / 10
+            x1 = sh2.local.scores(Qh[:1])[0]
+            t0 = time.perf_counter()
+            np.argsort(x1)[::-1]
+            extra["full_ranking_one_query"] = {"rows": rows2, "ms_per_query": dtr * 1e3, "host_argsort_ms": (time.perf_counter() - t0) * 1e3,
+                                               "note": "PCIe-inclusive: N int64 ids + N fp32 scores copied back"}
+        except Exception as e:
+            extra["full_ranking_one_query"] = {"error": repr(e)[:300]}
         sh2.local.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, np.concatenate(host_blocks), Qh, gpu_ids)

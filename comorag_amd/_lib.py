@@ -54,6 +54,7 @@ SIGNATURES = {
     "cmr_event_synchronize": (_i32, [_p]),
     "cmr_index_scores": (_i32, [_p, _p, _i32, _p, _i64]),
     "cmr_index_scores_dev": (_i32, [_p, _p, _i32, _p, _i64, _p]),
+    "cmr_index_sorted_scores": (_i32, [_p, _p, _i32, _p, _p, _p, _p]),
     "cmr_index_rescore": (_i32, [_p, _p, _i32, _p, _i32, _i32, _p, _p]),
     "cmr_index_get_rows": (_i32, [_p, _p, _i64, _p]),
     "cmr_merge_topk": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),

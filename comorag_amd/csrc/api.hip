@@ -771,6 +771,39 @@ int32_t cmr_index_scores(cmr_index_t* idx, const float* q, int32_t nq, float* ou
     return check_query_flag(ws);
 }
 
+int32_t cmr_index_sorted_scores(cmr_index_t* idx, const float* q, int32_t nq, int64_t* out_ids, float* out_scores, float* out_min,
+                                float* out_max) {
+    if (!idx || !q || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    const long long n = idx->n;
+    if (n == 0) return CMR_OK;
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, nullptr, false);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
+    hipStream_t s = ws->stream;
+    HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
+    HIP_TRY(ws->d_out.ensure((size_t)n * 4));
+    HIP_TRY(ws->d_cand.ensure(cmr_sort_workspace_bytes(n)));
+    HIP_TRY(ws->d_ids.ensure((size_t)n * 8));
+    HIP_TRY(ws->d_scores.ensure((size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
+    for (int qi = 0; qi < nq; ++qi) {
+        rc = scores_enqueue(idx, ws, (const float*)ws->d_q.p + (size_t)qi * idx->dim, 1, (float*)ws->d_out.p, n);
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        HIP_TRY(cmr_launch_sort_scores((const float*)ws->d_out.p, n, idx->id_base, ws->d_cand.p, (int64_t*)ws->d_ids.p,
+                                       (float*)ws->d_scores.p, s));
+        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)qi * n, ws->d_ids.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)qi * n, ws->d_scores.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));     // staging buffers are reused by the next query
+        if (out_max) out_max[qi] = out_scores[(size_t)qi * n];
+        if (out_min) out_min[qi] = out_scores[(size_t)qi * n + n - 1];
+    }
+    return check_query_flag(ws);
+}
+
 int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const int64_t* cand, int32_t n_cand, int32_t k,
                           int64_t* out_ids, float* out_scores) {
     if (!idx || !q || !cand || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");

@@ -514,6 +514,138 @@ hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq
 }
 
 // ------------------------------------------------------------------------------------------
+// Full descending sort of one query's N scores (ComoRAG.dense_passage_retrieval returns ALL N ids
+// by descending score, ComoRAG.py:964-966; graph_search_with_fact_entities consumes every pair,
+// :1034-1042).  Stable LSD radix sort, 4-bit digits, 8 passes over the complemented order-preserving
+// score code with the row index as payload: starting from ascending rows, stability yields exactly
+// the exported tie rule (score desc, row asc).  Per pass: per-tile digit histogram -> one exclusive
+// scan over [digit][tile] -> stable scatter (ballot ranks inside a wave, waves and 256-key slices
+// in order).
+#define SORT_TILE 2048
+#define SORT_THREADS 256
+
+__global__ __launch_bounds__(256) void sort_init_kernel(const float* __restrict__ scores, unsigned n, unsigned* __restrict__ code,
+                                                        unsigned* __restrict__ val) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) { code[i] = ~cmr_score_code(scores[i]); val[i] = i; }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const unsigned* __restrict__ code, unsigned n, int shift,
+                                                                  unsigned ntiles, unsigned* __restrict__ hist) {
+    __shared__ unsigned cnt[16];
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned base = blockIdx.x * SORT_TILE;
+    for (unsigned j = threadIdx.x; j < SORT_TILE; j += SORT_THREADS) {
+        const unsigned i = base + j;
+        if (i < n) atomicAdd(&cnt[(code[i] >> shift) & 15u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) hist[threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// exclusive scan of m = 16*ntiles counters, one workgroup (m is ~8 K at 1 M rows, ~78 K at 10 M)
+__global__ __launch_bounds__(1024) void sort_scan_kernel(unsigned* __restrict__ hist, unsigned m) {
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned carry_s;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < m; base += 1024 * 8) {
+        unsigned v[8], local = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const unsigned i = base + tid * 8 + j; v[j] = i < m ? hist[i] : 0u; local += v[j]; }
+        unsigned incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (unsigned w = 0; w < wave; ++w) wbase += wsum[w];
+        unsigned run = carry_s + wbase + incl - local;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const unsigned i = base + tid * 8 + j; if (i < m) hist[i] = run; run += v[j]; }
+        __syncthreads();
+        if (tid == 1023) carry_s = run;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const unsigned* __restrict__ code_in, const unsigned* __restrict__ val_in,
+                                                                     unsigned n, int shift, unsigned ntiles,
+                                                                     const unsigned* __restrict__ offs, unsigned* __restrict__ code_out,
+                                                                     unsigned* __restrict__ val_out) {
+    __shared__ unsigned run[16];          // keys of this tile already placed, per digit
+    __shared__ unsigned wcnt[4][16];      // per-wave digit counts of the current 256-key slice
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 16) run[tid] = offs[tid * ntiles + blockIdx.x];
+    __syncthreads();
+    const u64 lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (unsigned s = 0; s < SORT_TILE; s += SORT_THREADS) {
+        const unsigned i = blockIdx.x * SORT_TILE + s + tid;
+        const bool ok = i < n;
+        const unsigned c = ok ? code_in[i] : 0u;
+        const unsigned d = ok ? (c >> shift) & 15u : 16u;
+        unsigned rank = 0;
+#pragma unroll
+        for (unsigned v = 0; v < 16; ++v) {
+            const u64 b = __ballot(d == v);
+            if (d == v) rank = (unsigned)__popcll(b & lt);
+            if (lane == 0) wcnt[wave][v] = (unsigned)__popcll(b);
+        }
+        __syncthreads();
+        if (ok) {
+            unsigned pos = run[d] + rank;
+            for (unsigned w = 0; w < wave; ++w) pos += wcnt[w][d];
+            code_out[pos] = c;
+            val_out[pos] = val_in[i];
+        }
+        __syncthreads();
+        if (tid < 16) run[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void sort_finish_kernel(const unsigned* __restrict__ val, const float* __restrict__ scores, unsigned n,
+                                                          long long id_base, int64_t* __restrict__ out_ids,
+                                                          float* __restrict__ out_scores) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) { const unsigned r = val[i]; out_ids[i] = (int64_t)r + id_base; out_scores[i] = scores[r]; }
+}
+
+size_t cmr_sort_workspace_bytes(long long n) {
+    const size_t ntiles = (size_t)((n + SORT_TILE - 1) / SORT_TILE);
+    return (size_t)4 * n * 4 + 16 * ntiles * 4 + 256;
+}
+
+// scores [n] (device) -> out_ids [n], out_scores [n] sorted descending (ties: ascending row)
+hipError_t cmr_launch_sort_scores(const float* scores, long long n, long long id_base, void* workspace, int64_t* out_ids,
+                                  float* out_scores, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n >= (1ll << 32)) return hipErrorInvalidValue;
+    const unsigned un = (unsigned)n;
+    const unsigned ntiles = (un + SORT_TILE - 1) / SORT_TILE;
+    unsigned* code0 = reinterpret_cast<unsigned*>(workspace);
+    unsigned* val0 = code0 + n;
+    unsigned* code1 = val0 + n;
+    unsigned* val1 = code1 + n;
+    unsigned* hist = val1 + n;
+    const unsigned g256 = (un + 255) / 256;
+    hipLaunchKernelGGL(sort_init_kernel, dim3(g256), dim3(256), 0, s, scores, un, code0, val0);
+    unsigned *ci = code0, *vi = val0, *co = code1, *vo = val1;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 4 * pass;
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(SORT_THREADS), 0, s, ci, un, shift, ntiles, hist);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, hist, 16u * ntiles);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(SORT_THREADS), 0, s, ci, vi, un, shift, ntiles, hist, co, vo);
+        unsigned* t = ci; ci = co; co = t;
+        t = vi; vi = vo; vo = t;
+    }
+    hipLaunchKernelGGL(sort_finish_kernel, dim3(g256), dim3(256), 0, s, vi, scores, un, id_base, out_ids, out_scores);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Row access in the panel-major layout.
 template <int DT>
 __device__ __forceinline__ float cmr_load_elem(const unsigned char* corpus, int ks_total, long long row, int kidx) {

@@ -64,6 +64,10 @@ hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int n
 // per-row top-k (k <= 4096) of a materialised score matrix [nq, ld]
 hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq, int k, long long id_base,
                                 int64_t* out_ids, float* out_scores, float* out_min, float* out_max, hipStream_t s);
+// full descending sort of one query's scores (stable LSD radix sort; ties by ascending row)
+size_t cmr_sort_workspace_bytes(long long n);
+hipError_t cmr_launch_sort_scores(const float* scores, long long n, long long id_base, void* workspace, int64_t* out_ids,
+                                  float* out_scores, hipStream_t s);
 // shard merge: ids/scores [S][nq][k] -> [nq][k]
 hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int S, int nq, int k,
                                    int64_t* out_ids, float* out_scores, hipStream_t s);

@@ -174,6 +174,20 @@ class DenseIndex:
                                              C.c_void_p(out.data_ptr()), out.stride(0), C.c_void_p(stream)))
         return out
 
+    def sorted_scores(self, q):
+        """Complete ranking: (ids int64 [nq,N], raw scores fp32 [nq,N] descending, min [nq], max [nq])."""
+        q = _f32c(q)
+        if q.ndim == 1:
+            q = q[None, :]
+        n, nq = len(self), q.shape[0]
+        ids = np.empty((nq, n), dtype=np.int64)
+        sc = np.empty((nq, n), dtype=np.float32)
+        mn = np.empty(nq, dtype=np.float32)
+        mx = np.empty(nq, dtype=np.float32)
+        if n:
+            L.check(L.lib().cmr_index_sorted_scores(self._h, _ptr(q), nq, _ptr(ids), _ptr(sc), _ptr(mn), _ptr(mx)))
+        return ids, sc, mn, mx
+
     def rescore(self, q, cand, k: int) -> Tuple[np.ndarray, np.ndarray]:
         q = _f32c(q)
         if q.ndim == 1:

@@ -13,6 +13,7 @@ import numpy as np
 from .index import DenseIndex
 from .utils.misc_utils import min_max_normalize
 
+DEVICE_SORT_MIN_ROWS = 4096     # below this the host argsort of N floats is cheaper than 26 tiny launches
 QUERY_INSTRUCTION_SUMMARIES = "Given a question, retrieve relevant documents that best answer the question."
 
 
@@ -33,11 +34,17 @@ def dense_passage_retrieval(index: DenseIndex, query_embedding) -> Tuple[np.ndar
     """ComoRAG.dense_passage_retrieval (ComoRAG.py:950-967): ALL N ids by descending min-max
     normalised score + the scores in that order.  The N·D inner products come from the GPU; the
     normalise + argsort lines are the reference's."""
-    query_doc_scores = full_scores(index, query_embedding)
-    query_doc_scores = min_max_normalize(query_doc_scores)
-    sorted_doc_ids = np.argsort(query_doc_scores)[::-1]
-    sorted_doc_scores = query_doc_scores[sorted_doc_ids.tolist()]
-    return sorted_doc_ids, sorted_doc_scores
+    if len(index) < DEVICE_SORT_MIN_ROWS:          # tiny corpora: the reference's own lines on GPU scores
+        query_doc_scores = full_scores(index, query_embedding)
+        query_doc_scores = min_max_normalize(query_doc_scores)
+        sorted_doc_ids = np.argsort(query_doc_scores)[::-1]
+        sorted_doc_scores = query_doc_scores[sorted_doc_ids.tolist()]
+        return sorted_doc_ids, sorted_doc_scores
+    ids, raw, mn, mx = index.sorted_scores(_as_query(query_embedding)[:1])     # scan + stable radix sort on the GPU
+    rng = mx[0] - mn[0]
+    # min_max_normalize on the sorted vector (elementwise, order-independent): same fp32 formula
+    sorted_doc_scores = np.ones_like(raw[0]) if rng == 0 else (raw[0] - mn[0]) / rng
+    return ids[0], sorted_doc_scores
 
 
 def dense_passage_topk(index: DenseIndex, query_embeddings, k: int) -> Tuple[np.ndarray, np.ndarray]:

@@ -137,6 +137,13 @@ int32_t cmr_index_scores(cmr_index_t* idx, const float* q_f32, int32_t nq, float
 int32_t cmr_index_scores_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, float* out_dev,
                              int64_t ld, void* stream);
 
+/* ALL N rows of each query by descending raw score (ties: ascending row id), out_ids / out_scores
+ * [nq, N]; out_min / out_max [nq] (NULL allowed) are the last / first sorted score.  Replaces the
+ * np.dot + full argsort of ComoRAG.dense_passage_retrieval (ComoRAG.py:958-966) for callers that
+ * need the complete ranking: scan on MFMA, then a stable device radix sort.                       */
+int32_t cmr_index_sorted_scores(cmr_index_t* idx, const float* q_f32, int32_t nq, int64_t* out_ids,
+                                float* out_scores, float* out_min, float* out_max);
+
 /* Exact fp32 re-score of candidate rows (BASELINE config 5 "cross-scores on top-100").  The
  * reference's rerank.py is an LLM filter with no numeric scoring (rerank.py:100-123); this is
  * the numeric stage the engine adds behind the same (indices, items, {'confidence'}) shape.

@@ -188,6 +188,49 @@ def test_full_scores(dtype):
     idx.close()
 
 
+@pytest.mark.parametrize("dtype,n", [("bf16", 1), ("bf16", 2047), ("bf16", 2049), ("f32", 70001), ("bf16", 300017)])
+def test_sorted_scores_full_ranking(dtype, n):
+    """cmr_index_sorted_scores: all N rows, score descending, ties by ascending row — bit-identical
+    to sorting the library's own full-score vector with the exported rule."""
+    from comorag_amd.index import DenseIndex
+    d = 64
+    X, Q = _mk(n, d, 3, seed=21)
+    if n > 100:                         # exact ties: duplicate rows far apart, plus a block of identical rows
+        X[n // 2] = X[7]; X[n - 1] = X[7]; X[40:60] = X[40]
+    idx = DenseIndex(d, dtype); idx.append(X)
+    s = idx.scores(Q)
+    ids, sc, mn, mx = idx.sorted_scores(Q)
+    assert ids.shape == (3, n) and sc.shape == (3, n)
+    for i in range(3):
+        order = np.lexsort((np.arange(n), -s[i].astype(np.float64)))      # score desc, row asc
+        np.testing.assert_array_equal(ids[i], order)
+        np.testing.assert_array_equal(sc[i], s[i][order])
+        assert mx[i] == s[i].max() and mn[i] == s[i].min()
+    exact = orc.exact_scores_f64(ROUND[dtype](X), ROUND[dtype](Q))
+    np.testing.assert_allclose(sc, np.take_along_axis(exact, ids, 1), atol=ERR, rtol=0)
+    idx.close()
+
+
+def test_dense_passage_retrieval_device_sort_matches_reference_lines():
+    """retrieval.dense_passage_retrieval above DEVICE_SORT_MIN_ROWS (device sort) returns what the
+    reference's normalise + argsort lines give on the same scores (ComoRAG.py:950-967), ties aside."""
+    from comorag_amd import retrieval
+    from comorag_amd.index import DenseIndex
+    n, d = 20011, 96
+    assert n >= retrieval.DEVICE_SORT_MIN_ROWS
+    X, Q = _mk(n, d, 1, seed=22)
+    idx = DenseIndex(d, "f32"); idx.append(X)
+    ids, sc = retrieval.dense_passage_retrieval(idx, Q[0])
+    ref_ids, ref_sc = orc.dense_passage_retrieval(X, Q[0])
+    assert ids.shape == (n,) and ids.dtype == np.int64
+    np.testing.assert_allclose(sc, ref_sc, atol=2e-6, rtol=0)
+    exact = orc.exact_scores_f64(X, Q)[0]
+    orc.assert_topk_equivalent(ids, ref_ids, exact, 1e-6)
+    assert sc[0] == 1.0 and sc[-1] == 0.0 and np.all(np.diff(sc) <= 0)
+    assert sorted(ids.tolist()) == list(range(n))
+    idx.close()
+
+
 def test_nonfinite_rejected():
     from comorag_amd.index import DenseIndex
     from comorag_amd._lib import CmrError, CMR_ERR_NONFINITE
