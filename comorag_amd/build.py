@@ -142,6 +142,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(os.path.join(tmp, "scan_kernels.o"))
         asm_file = os.path.join(tmp, f"scan_kernels-hip-amdgcn-amd-amdhsa-{ARCH}.s")
         audit = audit_ring(open(asm_file).read())
+        if not audit:       # the mangled-name pattern no longer matches: every variant would silently lose its ring
+            raise RuntimeError("ISA audit found no scan_kernel<..., ASMRING=1> in the assembly; update _KERNEL_RE")
         # 2. audit table
         rows = ",\n".join(f"    {{{dt}, {nqt}, {cap}, {ring}, {mode}, {1 if ok else 0}}}"
                           for (dt, nqt, cap, ring, mode), ok in sorted(audit.items()))

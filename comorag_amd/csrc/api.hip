@@ -117,7 +117,7 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
-    int reserve_cus = 96;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves to the next pass's pre-phase (160 CUs still saturate HBM)
+    int reserve_cus = 64;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves to the next pass's pre-phase
     std::mutex pipe_mu;
     Pipe pipe;
     size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
@@ -246,7 +246,7 @@ int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, in
 // goes to `sp`, the main scan + candidate merge to `sm`; when the two differ (pipelined mode) an
 // event orders them, so the pre-phase of the NEXT pass/batch can overlap this pass's main scan.
 int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, hipStream_t sq, hipEvent_t ev_pre, hipEvent_t ev_scan,
-                 const float* q_dev, int nqp,
+                 hipEvent_t ev_lists_free, const float* q_dev, int nqp,
                  int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false) {
     CmrScanGeom g;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
@@ -319,6 +319,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         a.tau_init = tau_out;
     }
     if (sp != sm) {
+        if (ev_lists_free) HIP_TRY(hipStreamWaitEvent(sp, ev_lists_free, 0));   // previous merge of this slot's lists
         HIP_TRY(hipEventRecord(ev_pre, sp));
         HIP_TRY(hipStreamWaitEvent(sm, ev_pre, 0));
     }
@@ -360,11 +361,26 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         const int left = nq - q0;
         const bool wide = wideq > 0 && left > narrow;          // more than one narrow pass left: go wide
         const int nqp = std::min(wide ? wideq : narrow, left);
-        int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
+        int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
         q0 += nqp;
+    }
+    return CMR_OK;
+}
+
+// Streams and per-slot events of the pipelined search, created on first use (idx->pipe_mu held).
+int ensure_pipe(Pipe& P) {
+    if (P.sp) return CMR_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&P.slot[i].scan_done, hipEventDisableTiming));
+        P.slot[i].ws.stream = P.sm;
     }
     return CMR_OK;
 }
@@ -376,17 +392,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
                              float* max_dev, hipEvent_t wait_event, hipEvent_t* done_event) {
     std::lock_guard<std::mutex> pl(idx->pipe_mu);
     Pipe& P = idx->pipe;
-    if (!P.sp) {
-        HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].scan_done, hipEventDisableTiming));
-            P.slot[i].ws.stream = P.sm;
-        }
-    }
+    { int rc_ = ensure_pipe(P); if (rc_) return rc_; }
     if (wait_event) HIP_TRY(hipStreamWaitEvent(P.sp, wait_event, 0));
     if (k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "pipelined search supports k <= %d", CMR_MAX_K);
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
@@ -398,9 +404,16 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         const bool wide = wideq > 0 && left > narrow;
         const int nqp = std::min(wide ? wideq : narrow, left);
         PipeSlot* sl = &P.slot[P.next++ & 1];
-        if (sl->used) HIP_TRY(hipStreamWaitEvent(P.sp, sl->main_done, 0));   // its buffers are free again
+        if (sl->used) {
+            // The pre-phase rewrites the slot's query fragments / thresholds: free once the slot's previous
+            // main scan is over.  Its candidate lists are still being merged (on sq) at that point, so only the
+            // new MAIN scan waits for that merge — a full scan period later, i.e. never in practice; that wait
+            // sits at the END of the pre-phase (enqueue_pass, before pre_done is recorded): every wait packet on
+            // the scan stream itself costs ~10 us between two main scans.
+            HIP_TRY(hipStreamWaitEvent(P.sp, sl->scan_done, 0));
+        }
         // the wide kernel is MFMA-bound, not HBM-bound: it keeps every CU
-        int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, q_dev + (size_t)q0 * idx->dim, nqp, k,
+        int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
                               wide ? 0 : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
@@ -539,7 +552,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
-    idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", 96);
+    idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", 64);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);
@@ -680,16 +693,8 @@ int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream
     if (rc) return rc;
     std::lock_guard<std::mutex> pl(idx->pipe_mu);
     Pipe& P = idx->pipe;
-    if (!P.sp) {
-        HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
-            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&P.slot[i].scan_done, hipEventDisableTiming));
-        }
-    }
+    rc = ensure_pipe(P);
+    if (rc) return rc;
     *stream = which == 0 ? (void*)P.sp : which == 1 ? (void*)P.sm : (void*)P.sq;
     return CMR_OK;
 }
