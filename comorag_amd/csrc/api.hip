@@ -117,7 +117,7 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
-    int reserve_cus = 64;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves to the next pass's pre-phase
+    int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS (-1 = by corpus size, see pipe_reserve_cus)
     std::mutex pipe_mu;
     Pipe pipe;
     size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
@@ -242,6 +242,21 @@ int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, in
     return CMR_OK;
 }
 
+// Every wave (workgroup, for the wide kernel) scans a contiguous range of floor/ceil(npanels / W) panels and
+// the kernel ends with the longest range: at 1 M rows on 256 CUs that is 16 panels against a mean of 15.3,
+// a 5 % tail during which HBM idles.  The scan is bandwidth-bound, not CU-bound, so giving up a few workgroups
+// (<= 1/8) for the W that minimises the padded panel count ceil(npanels / W) * W is free.
+int balanced_grid(long long npanels, int grid, int lists_per_wg) {
+    int best = grid;
+    long long best_padded = -1;
+    for (int g = grid; g >= std::max(1, grid - grid / 8); --g) {
+        const long long W = (long long)g * lists_per_wg;
+        const long long padded = (npanels + W - 1) / W * W;
+        if (best_padded < 0 || padded < best_padded) { best_padded = padded; best = g; }
+    }
+    return best;
+}
+
 // One pass (<= 64 queries) of the fused search.  The pre-phase (query packing + sampling levels)
 // goes to `sp`, the main scan + candidate merge to `sm`; when the two differ (pipelined mode) an
 // event orders them, so the pre-phase of the NEXT pass/batch can overlap this pass's main scan.
@@ -264,9 +279,11 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         g.nqt = 1;
         g.grid = (int)std::max<long long>(1, std::min<long long>(npanels, idx->n_cu));
         if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        g.grid = balanced_grid(npanels, g.grid, 1);
         NQ = nqb; W = g.grid; tiles = nqb / 32;
     } else {
         if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        if (!idx->force_grid) g.grid = balanced_grid(npanels, g.grid, CMR_SCAN_WAVES);
         NQ = g.nqt * 32; W = g.grid * CMR_SCAN_WAVES; tiles = g.nqt;
     }
     const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
@@ -370,6 +387,16 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
     return CMR_OK;
 }
 
+// CUs the pipelined main scan leaves free for the next batch's pre-phase (its sampling workgroups need 106 KiB
+// of LDS and cannot share a CU with a scan workgroup).  Leaving 64 free costs the scan ~3 % of its bandwidth and
+// saves ~60 us of exposed pre-phase per step (measured at 1 M, 1.25 M and 10 M rows): worth it below ~2 ms of
+// scan, i.e. ~12 GB of corpus per device.  CMR_PIPE_RESERVE_CUS >= 0 overrides.
+int pipe_reserve_cus(const cmr_index* idx) {
+    if (idx->reserve_cus >= 0) return idx->reserve_cus;
+    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    return (double)npanels * idx->panel_bytes() > 12e9 ? 0 : 64;
+}
+
 // Streams and per-slot events of the pipelined search, created on first use (idx->pipe_mu held).
 int ensure_pipe(Pipe& P) {
     if (P.sp) return CMR_OK;
@@ -414,7 +441,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         }
         // the wide kernel is MFMA-bound, not HBM-bound: it keeps every CU
         int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
-                              wide ? 0 : idx->reserve_cus,
+                              wide ? 0 : pipe_reserve_cus(idx),
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
@@ -552,7 +579,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
-    idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", 64);
+    idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);
