@@ -117,7 +117,7 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
-    int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS (-1 = by corpus size, see pipe_reserve_cus)
+    int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves free (-1 = by corpus size, see enqueue_pass)
     std::mutex pipe_mu;
     Pipe pipe;
     size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
@@ -271,21 +271,6 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     }
     int rc = make_geom(idx, nqp, k, true, &g);
     if (rc) return rc;
-    int NQ, W, tiles;
-    if (wide) {
-        // register-resident queries: 32 per wave, 8 or 4 waves per workgroup, one list row per
-        // (workgroup, query); one workgroup per CU
-        const int nqb = cmr_wide_queries(idx->dtype, idx->dpad);
-        g.nqt = 1;
-        g.grid = (int)std::max<long long>(1, std::min<long long>(npanels, idx->n_cu));
-        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
-        g.grid = balanced_grid(npanels, g.grid, 1);
-        NQ = nqb; W = g.grid; tiles = nqb / 32;
-    } else {
-        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
-        if (!idx->force_grid) g.grid = balanced_grid(npanels, g.grid, CMR_SCAN_WAVES);
-        NQ = g.nqt * 32; W = g.grid * CMR_SCAN_WAVES; tiles = g.nqt;
-    }
     const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
     // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
     // best of that sample per query as the threshold of the next level / of the main scan.  Any
@@ -305,6 +290,32 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     }
     const long long max_sample = std::max(level_panels[0], level_panels[1]);
     const int Ws = max_sample ? (int)((max_sample + lists_per_wg - 1) / lists_per_wg) * lists_per_wg : 0;
+    if (reserve_cus < 0) {
+        // Pipelined mode, reserve chosen by size: the next batch's pre-phase (~200 us of dependent small kernels
+        // plus ~45 us per round of its largest sampling pass on the reserved CUs) has to fit under this scan
+        // (~6 TB/s); every reserved CU costs the scan bandwidth (64 of 256: ~3 %).  Measured at 1 M / 1.25 M /
+        // 10 M rows x 768 bf16: 64 CUs is best for sub-millisecond scans, a handful is enough for long ones.
+        const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
+        const long long rounds = (long long)((0.7 * scan_us - 200.0) / 45.0);
+        const long long wgs = std::max<long long>(1, Ws / lists_per_wg);
+        reserve_cus = rounds >= 1 ? (int)std::min<long long>(64, std::max<long long>(8, (wgs + rounds - 1) / rounds)) : 64;
+        if (!Ws) reserve_cus = 0;
+    }
+    int NQ, W, tiles;
+    if (wide) {
+        // register-resident queries: 32 per wave, 8 or 4 waves per workgroup, one list row per
+        // (workgroup, query); one workgroup per CU
+        const int nqb = cmr_wide_queries(idx->dtype, idx->dpad);
+        g.nqt = 1;
+        g.grid = (int)std::max<long long>(1, std::min<long long>(npanels, idx->n_cu));
+        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        g.grid = balanced_grid(npanels, g.grid, 1);
+        NQ = nqb; W = g.grid; tiles = nqb / 32;
+    } else {
+        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        if (!idx->force_grid) g.grid = balanced_grid(npanels, g.grid, CMR_SCAN_WAVES);
+        NQ = g.nqt * 32; W = g.grid * CMR_SCAN_WAVES; tiles = g.nqt;
+    }
     // sample passes and the main pass use separate list buffers: in pipelined mode the next batch's
     // sampling runs while this batch's main scan still owns `lists`
     HIP_TRY(ws->qfrag.ensure((size_t)tiles * g.ks * 1024));
@@ -387,16 +398,6 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
     return CMR_OK;
 }
 
-// CUs the pipelined main scan leaves free for the next batch's pre-phase (its sampling workgroups need 106 KiB
-// of LDS and cannot share a CU with a scan workgroup).  Leaving 64 free costs the scan ~3 % of its bandwidth and
-// saves ~60 us of exposed pre-phase per step (measured at 1 M, 1.25 M and 10 M rows): worth it below ~2 ms of
-// scan, i.e. ~12 GB of corpus per device.  CMR_PIPE_RESERVE_CUS >= 0 overrides.
-int pipe_reserve_cus(const cmr_index* idx) {
-    if (idx->reserve_cus >= 0) return idx->reserve_cus;
-    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-    return (double)npanels * idx->panel_bytes() > 12e9 ? 0 : 64;
-}
-
 // Streams and per-slot events of the pipelined search, created on first use (idx->pipe_mu held).
 int ensure_pipe(Pipe& P) {
     if (P.sp) return CMR_OK;
@@ -441,7 +442,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         }
         // the wide kernel is MFMA-bound, not HBM-bound: it keeps every CU
         int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
-                              wide ? 0 : pipe_reserve_cus(idx),
+                              wide ? 0 : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
