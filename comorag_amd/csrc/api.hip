@@ -245,14 +245,16 @@ int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, in
 // Every wave (workgroup, for the wide kernel) scans a contiguous range of floor/ceil(npanels / W) panels and
 // the kernel ends with the longest range: at 1 M rows on 256 CUs that is 16 panels against a mean of 15.3,
 // a 5 % tail during which HBM idles.  The scan is bandwidth-bound, not CU-bound, so giving up a few workgroups
-// (<= 1/8) for the W that minimises the padded panel count ceil(npanels / W) * W is free.
+// (<= 1/8) for the W that minimises the padded panel count ceil(npanels / W) * W is free.  (Not for the wide
+// kernel: it is MFMA-bound and wants every CU.)
 int balanced_grid(long long npanels, int grid, int lists_per_wg) {
+    // a dropped workgroup is not quite free (64 of 256 CUs cost ~3 % of the bandwidth): charge 0.05 % each
     int best = grid;
-    long long best_padded = -1;
+    double best_cost = -1.0;
     for (int g = grid; g >= std::max(1, grid - grid / 8); --g) {
         const long long W = (long long)g * lists_per_wg;
-        const long long padded = (npanels + W - 1) / W * W;
-        if (best_padded < 0 || padded < best_padded) { best_padded = padded; best = g; }
+        const double cost = (double)((npanels + W - 1) / W * W) * (1.0 + 0.0005 * (grid - g));
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = g; }
     }
     return best;
 }
@@ -291,12 +293,14 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     const long long max_sample = std::max(level_panels[0], level_panels[1]);
     const int Ws = max_sample ? (int)((max_sample + lists_per_wg - 1) / lists_per_wg) * lists_per_wg : 0;
     if (reserve_cus < 0) {
-        // Pipelined mode, reserve chosen by size: the next batch's pre-phase (~200 us of dependent small kernels
-        // plus ~45 us per round of its largest sampling pass on the reserved CUs) has to fit under this scan
-        // (~6 TB/s); every reserved CU costs the scan bandwidth (64 of 256: ~3 %).  Measured at 1 M / 1.25 M /
-        // 10 M rows x 768 bf16: 64 CUs is best for sub-millisecond scans, a handful is enough for long ones.
+        // Pipelined mode, reserve chosen by size: the next batch's pre-phase has to fit under this scan (~6 TB/s).
+        // It is ~200 us of dependent small kernels plus ~200 us per round of its largest sampling pass on the
+        // reserved CUs (every sampling workgroup stages the 96 KiB query tile and its loads crawl while the scan
+        // saturates HBM: at 10 M rows 320 workgroups on 26 CUs took 2.3 ms and overran the scan by 90 us, on 34
+        // CUs they fit).  Reserved CUs cost the scan bandwidth only at short scans (64 of 256: ~3 % at 1 M rows,
+        // nothing measurable at 10 M).  Measured at 1 / 1.25 / 2.5 / 5 / 10 M rows x 768 bf16.
         const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
-        const long long rounds = (long long)((0.7 * scan_us - 200.0) / 45.0);
+        const long long rounds = (long long)((0.7 * scan_us - 200.0) / 200.0);
         const long long wgs = std::max<long long>(1, Ws / lists_per_wg);
         reserve_cus = rounds >= 1 ? (int)std::min<long long>(64, std::max<long long>(8, (wgs + rounds - 1) / rounds)) : 64;
         if (!Ws) reserve_cus = 0;
@@ -309,7 +313,6 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         g.nqt = 1;
         g.grid = (int)std::max<long long>(1, std::min<long long>(npanels, idx->n_cu));
         if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
-        g.grid = balanced_grid(npanels, g.grid, 1);
         NQ = nqb; W = g.grid; tiles = nqb / 32;
     } else {
         if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
