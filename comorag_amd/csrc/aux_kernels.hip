@@ -769,12 +769,29 @@ struct f16_t { unsigned short v; };
 template <> __device__ __forceinline__ float cmr_to_f<bf16_t>(bf16_t v) { return cmr_bf2f(v.v); }
 template <> __device__ __forceinline__ float cmr_to_f<f16_t>(f16_t v) { return cmr_h2f(v.v); }
 
+// Latency, not bandwidth, was the first bound here (34 us for 40 MB at b = 32: each token row was a mask load, a
+// branch and a dependent 16-B load).  Both kernels now issue their loads in batches of POOL_U before the first add;
+// the adds keep the token / split order, so the sums are bit-identical to the sequential loop.
+#define POOL_U 8
 template <typename T>
 __global__ __launch_bounds__(256) void pool_partial_kernel(const T* __restrict__ hidden, const int64_t* __restrict__ mask, int l,
                                                            int d, int splits, float* __restrict__ partial) {
     const int b = blockIdx.x, sp = blockIdx.y;
     const int per = (l + splits - 1) / splits;
     const int t0 = sp * per, t1 = min(l, t0 + per);
+    const int64_t* mrow = mask + (size_t)b * l;
+    // attention mask of this split as bit sets, one coalesced load per 64 tokens, taken before any lane drops out
+    // of the column loop (host keeps `per` <= 256, cmr_pool_splits; longer splits use the per-token loads)
+    const int lane = threadIdx.x & 63;
+    const bool bitmask = per <= 256;
+    u64 bits[4] = {0ull, 0ull, 0ull, 0ull};
+    if (bitmask) {
+#pragma unroll
+        for (int cidx = 0; cidx < 4; ++cidx) {
+            const int tt = t0 + cidx * 64 + lane;
+            bits[cidx] = __ballot(tt < t1 && mrow[tt < l ? tt : 0] != 0);
+        }
+    }
     // each thread owns columns tid*VEC .. (+VEC) strided by 256*VEC: loads are contiguous per token row
     constexpr int VEC = 16 / sizeof(T);
     for (int c0 = threadIdx.x * VEC; c0 < d; c0 += 256 * VEC) {
@@ -782,15 +799,32 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
         const bool full = c0 + VEC <= d && (d % VEC) == 0;
-        for (int t = t0; t < t1; ++t) {
-            if (mask[(size_t)b * l + t] == 0) continue;   // uniform across the block
-            const T* rowp = hidden + ((size_t)b * l + t) * d + c0;
-            if (full) {
-                const uint4 raw = *reinterpret_cast<const uint4*>(rowp);
-                const T* e4 = reinterpret_cast<const T*>(&raw);
+        if (full && bitmask) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[e] += cmr_to_f<T>(e4[e]);
-            } else {
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const u64 bs = bits[cidx];
+                if (bs == 0ull) continue;
+                const int tc = t0 + cidx * 64;
+                for (int j0 = 0; j0 < 64 && (bs >> j0) != 0ull; j0 += POOL_U) {
+                    uint4 raw[POOL_U];
+#pragma unroll
+                    for (int j = 0; j < POOL_U; ++j)
+                        raw[j] = ((bs >> (j0 + j)) & 1ull)
+                                     ? *reinterpret_cast<const uint4*>(hidden + ((size_t)b * l + tc + j0 + j) * d + c0)
+                                     : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int j = 0; j < POOL_U; ++j) {
+                        if (!((bs >> (j0 + j)) & 1ull)) continue;
+                        const T* e4 = reinterpret_cast<const T*>(&raw[j]);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) acc[e] += cmr_to_f<T>(e4[e]);
+                    }
+                }
+            }
+        } else {
+            for (int t = t0; t < t1; ++t) {
+                if (mrow[t] == 0) continue;
+                const T* rowp = hidden + ((size_t)b * l + t) * d + c0;
                 for (int e = 0; e < VEC; ++e) if (c0 + e < d) acc[e] += cmr_to_f<T>(rowp[e]);
             }
         }
@@ -817,7 +851,13 @@ __global__ __launch_bounds__(256) void pool_finalize_kernel(const float* __restr
     float ss = 0.0f;
     for (int cx = tid; cx < d; cx += 256) {
         float s = 0.0f;
-        for (int sp = 0; sp < splits; ++sp) s += partial[((size_t)b * splits + sp) * d + cx];
+        for (int sp = 0; sp < splits; sp += POOL_U) {
+            float v[POOL_U];
+#pragma unroll
+            for (int j = 0; j < POOL_U; ++j) v[j] = sp + j < splits ? partial[((size_t)b * splits + sp + j) * d + cx] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < POOL_U; ++j) if (sp + j < splits) s += v[j];
+        }
         s = s / count;
         out[(size_t)b * d + cx] = s;
         ss += s * s;
@@ -837,6 +877,7 @@ int cmr_pool_splits(int b, int l, int d) {
     int s = (1024 + b - 1) / b;
     if (s > l / 8) s = l / 8;
     if (s < 1) s = 1;
+    if (s < (l + 255) / 256) s = (l + 255) / 256;     // <= 256 tokens per split: the kernel's bit-set fast path
     if (s > 64) s = 64;
     (void)d;
     return s;
