@@ -1,5 +1,6 @@
-"""BASELINE configs 4 and 5 as parity cases (configs 1-3 are covered in test_oracle_pin.py,
-test_search_gpu.py::test_c2_size_properties and the logical-shard / gloo tests)."""
+"""BASELINE configs 3, 4 and 5 as parity cases at their full sizes (configs 1-2 are covered in
+test_oracle_pin.py and test_search_gpu.py::test_c2_size_properties; small-size sharding in the
+logical-shard / gloo tests)."""
 import numpy as np
 import pytest
 
@@ -87,3 +88,46 @@ def test_config5_encode_then_search_then_rescore():
         orc.assert_topk_equivalent(ids[i], want, ex32[i], 1e-6)
         np.testing.assert_allclose(sc[i], ex32[i][ids[i]], atol=1e-6)
     idx.close()
+
+
+def test_config3_full_size_eight_shards_equal_one_index():
+    """BASELINE config 3 at its full size on one device: 10 M x 768 bf16 rows as 8 row shards of
+    1.25 M (global ids via cmr_index_set_id_base), batch 256, k = 20, per-shard top-k + final merge.
+    Size-independent properties: the merged result is bit-identical to ONE 10 M-row index (a row's
+    score is the same fp32 chain wherever the row lives), planted neighbours come back first with
+    their global id, scores are sorted, the global min/max are the extremes over the shards."""
+    import torch
+    from comorag_amd.index import DenseIndex, merge_topk
+    rows, dim, S, B, k, blk = 10_000_000, 768, 8, 256, 20, 250_000
+    per = rows // S
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(31337)
+    single = DenseIndex(dim, "bf16", capacity_hint=rows)
+    shards = [DenseIndex(dim, "bf16", capacity_hint=per) for _ in range(S)]
+    for s, sh in enumerate(shards):
+        sh.set_id_base(s * per)
+    planted_ids, planted_rows = [], []
+    for b0 in range(0, rows, blk):
+        x = torch.randn((blk, dim), generator=g, device=dev)
+        x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+        single.append_dev(x)
+        shards[b0 // per].append_dev(x)
+        planted_ids.append(b0 + 4321); planted_rows.append(x[4321].clone())
+    del x
+    q = torch.randn((B, dim), generator=g, device=dev)
+    npl = len(planted_ids)                                           # 40 planted queries, 216 random ones
+    q[:npl] = torch.stack(planted_rows) + 0.01 * q[:npl]           # |noise| ~ 0.28 -> cos ~ 0.96
+    q = (q / q.norm(dim=1, keepdim=True)).cpu().numpy()
+    ids1, sc1, mn1, mx1 = single.search(q, k)
+    parts = [sh.search(q, k) for sh in shards]
+    ids2, sc2 = merge_topk(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+    assert np.array_equal(ids1, ids2) and np.array_equal(sc1, sc2)
+    assert np.array_equal(ids1[:npl, 0], np.asarray(planted_ids))
+    assert np.all(sc1[:npl, 0] > 0.9)
+    assert np.all(np.diff(sc1, axis=1) <= 0) and np.all(ids1 >= 0) and np.all(ids1 < rows)
+    assert all(len(set(r.tolist())) == k for r in ids1)
+    assert np.array_equal(mx1, sc1[:, 0]) and np.array_equal(mx1, np.max([p[3] for p in parts], axis=0))
+    assert np.array_equal(mn1, np.min([p[2] for p in parts], axis=0)) and np.all(mn1 <= sc1[:, -1])
+    single.close()
+    for sh in shards:
+        sh.close()
