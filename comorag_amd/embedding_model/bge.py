@@ -10,7 +10,7 @@ the reference:
   * `encode(list)` positional returns a torch tensor [n, D] (memory_utils.py:176,205,297 index it).
 Fixed consciously: `max_length` is clamped to the model's `max_position_embeddings` (the reference
 default 2048 overflows BERT's 512 positions), `embedding_model_dtype` is honoured, and
-tokenisation of mini-batch i+1 overlaps the forward of mini-batch i.
+tokenisation of the next mini-batches (a pool of host threads) overlaps the forward of mini-batch i.
 """
 from __future__ import annotations
 
@@ -27,6 +27,17 @@ from .base import BaseEmbeddingModel, EmbeddingConfig, make_cache_embed
 
 BGE_PREFIX = "Generate a representation for this sentence to retrieve relevant articles:"
 _TORCH_TO_CMR = {"torch.float32": L.CMR_F32, "torch.bfloat16": L.CMR_BF16, "torch.float16": L.CMR_F16}
+
+
+def tokenize_batch(tokenizer, prompts: List[str], max_length: int):
+    """`tokenizer(prompts, padding=True, truncation=True, max_length=..., return_tensors="pt")` of
+    BGEEmbedding.py:112-117 with the same int64 tensors, minus transformers' pure-Python
+    `flatten()` of every id list during tensor conversion (a third of the call at 32 x 512 tokens,
+    all of it under the GIL — it competes with the thread that launches the encoder's kernels).
+    The Rust `encode_batch` underneath releases the GIL, so several of these run concurrently."""
+    import torch
+    enc = tokenizer(prompts, padding=True, truncation=True, max_length=int(max_length), return_tensors=None)
+    return {k: torch.from_numpy(np.asarray(v, dtype=np.int64)) for k, v in enc.items()}
 
 
 def pool_l2norm(hidden, mask, normalize: bool = True):
@@ -72,7 +83,9 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self.embedding_model.eval()
         self.embedding_dim = self.embedding_model.config.hidden_size
         self.max_positions = int(getattr(self.embedding_model.config, "max_position_embeddings", 1 << 30))
-        self._tok_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cmr-tok")
+        import os
+        self._tok_workers = max(1, min(int(cfg_get(self.global_config, "embedding_tokenizer_threads", 8)), os.cpu_count() or 1))
+        self._tok_pool = ThreadPoolExecutor(max_workers=self._tok_workers, thread_name_prefix="cmr-tok")
         if cfg_get(self.global_config, "embedding_cache_enabled", False):
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
             self.encode = make_cache_embed(self._encode, path, self.device)
@@ -92,8 +105,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
 
     # ------------------------------------------------------------------ one mini-batch
     def _tokenize(self, prompts: List[str], max_length: int):
-        return self.tokenizer(prompts, padding=True, truncation=True,
-                              max_length=min(int(max_length), self.max_positions), return_tensors="pt")
+        return tokenize_batch(self.tokenizer, prompts, min(int(max_length), self.max_positions))
 
     def _forward_pool(self, inputs, normalize: bool):
         import torch
@@ -137,19 +149,22 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     parts.append(self.encode(**params))
                 results = torch.cat(parts, dim=0)
         else:
-            # same mini-batches as the reference loop (:168-175); tokenisation of batch i+1 runs on a
-            # host thread while batch i is on the GPU
+            # same mini-batches as the reference loop (:168-175); the next `_tok_workers` mini-batches are
+            # tokenised on host threads while batch i is on the GPU (one tokeniser thread kept the bf16
+            # encoder waiting: ~1 ms of WordPiece per 512-token chunk against 0.17 ms of forward)
             instr = params.get("instruction", "")
             max_length = params.get("max_length", 512)
             normalize = params.get("normalize", True)
             chunks = [texts[i:i + batch_size] for i in range(0, len(texts), batch_size)]
             prep = lambda c: self._tokenize([instr + t for t in c] if instr else list(c), max_length)
-            fut = self._tok_pool.submit(prep, chunks[0])
+            ahead = self._tok_workers + 1
+            futs = [self._tok_pool.submit(prep, c) for c in chunks[:ahead]]
             parts = []
             for i in range(len(chunks)):
-                inputs = fut.result()
-                if i + 1 < len(chunks):
-                    fut = self._tok_pool.submit(prep, chunks[i + 1])
+                inputs = futs[i].result()
+                futs[i] = None
+                if i + ahead < len(chunks):
+                    futs.append(self._tok_pool.submit(prep, chunks[i + ahead]))
                 parts.append(self._forward_pool(inputs, normalize))
             results = torch.cat(parts, dim=0)
         if isinstance(results, torch.Tensor):

@@ -145,3 +145,23 @@ def test_sidecar_persistence_is_append_only_and_equivalent(tmp_path, fake_embedd
     c.insert_strings(["brand new"])
     c2 = EmbeddingStore(FakeEmbedder(32), str(tmp_path / "p"), 8, "chunk", persist="sidecar")
     assert c2.hash_ids == a.hash_ids + [compute_mdhash_id("brand new", prefix="chunk-")]
+
+
+def test_tokenize_batch_equals_the_reference_tokenizer_call():
+    """comorag_amd.embedding_model.bge.tokenize_batch must hand the encoder exactly what
+    BGEEmbedding.py:112-117 does (`tokenizer(prompts, padding=True, truncation=True, max_length=...,
+    return_tensors="pt")`): same keys, int64 tensors, padding to the longest prompt, truncation."""
+    import torch
+    from comorag_amd.embedding_model.bge import tokenize_batch
+    from comorag_amd.utils.synthetic import synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer()
+    chunks = synthetic_chunks(words, 8)
+    texts = chunks[:5] + ["", "a", chunks[5][:50], "   ", chunks[6] * 3]
+    for max_length in (512, 16, 3):
+        ref = tok(texts, padding=True, truncation=True, max_length=max_length, return_tensors="pt")
+        got = tokenize_batch(tok, texts, max_length)
+        assert set(ref.keys()) == set(got.keys())
+        for key in ref:
+            assert got[key].dtype == ref[key].dtype == torch.int64 and torch.equal(got[key], ref[key]), key
+    one = tokenize_batch(tok, [texts[0]], 512)
+    assert one["input_ids"].ndim == 2 and one["input_ids"].shape[0] == 1
