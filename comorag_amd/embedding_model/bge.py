@@ -33,8 +33,7 @@ def tokenize_batch(tokenizer, prompts: List[str], max_length: int):
     """`tokenizer(prompts, padding=True, truncation=True, max_length=..., return_tensors="pt")` of
     BGEEmbedding.py:112-117 with the same int64 tensors, minus transformers' pure-Python
     `flatten()` of every id list during tensor conversion (a third of the call at 32 x 512 tokens,
-    all of it under the GIL — it competes with the thread that launches the encoder's kernels).
-    The Rust `encode_batch` underneath releases the GIL, so several of these run concurrently."""
+    all of it under the GIL — it competes with the thread that launches the encoder's kernels)."""
     import torch
     enc = tokenizer(prompts, padding=True, truncation=True, max_length=int(max_length), return_tensors=None)
     return {k: torch.from_numpy(np.asarray(v, dtype=np.int64)) for k, v in enc.items()}
@@ -84,7 +83,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self.embedding_dim = self.embedding_model.config.hidden_size
         self.max_positions = int(getattr(self.embedding_model.config, "max_position_embeddings", 1 << 30))
         import os
-        self._tok_workers = max(1, min(int(cfg_get(self.global_config, "embedding_tokenizer_threads", 8)), os.cpu_count() or 1))
+        self._tok_workers = max(1, min(int(cfg_get(self.global_config, "embedding_tokenizer_threads", 2)), os.cpu_count() or 1))
         self._tok_pool = ThreadPoolExecutor(max_workers=self._tok_workers, thread_name_prefix="cmr-tok")
         if cfg_get(self.global_config, "embedding_cache_enabled", False):
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
@@ -149,9 +148,9 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     parts.append(self.encode(**params))
                 results = torch.cat(parts, dim=0)
         else:
-            # same mini-batches as the reference loop (:168-175); the next `_tok_workers` mini-batches are
-            # tokenised on host threads while batch i is on the GPU (one tokeniser thread kept the bf16
-            # encoder waiting: ~1 ms of WordPiece per 512-token chunk against 0.17 ms of forward)
+            # same mini-batches as the reference loop (:168-175); the next mini-batches are tokenised on host
+            # threads while batch i is on the GPU.  tokenizers 0.22 holds the GIL in encode_batch, so more
+            # than a couple of workers buys nothing (measured 1 vs 8 threads: 4134 vs 4092 chunks/s)
             instr = params.get("instruction", "")
             max_length = params.get("max_length", 512)
             normalize = params.get("normalize", True)
