@@ -412,17 +412,19 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 #define WIDE_GROUP 8      // blocks per staged group
 #define WIDE_STAGES 12    // LDS ring depth in groups (96 KiB)
 
-template <int DT, int KS, int WAVES, int CAP, int ABL = 0>   // ABL: developer ablation (1 no MFMA, 2 no DMA, 3 no barrier)
+// GRP blocks per staged group, NSTG groups in the LDS ring (GRP * NSTG = 96 KiB).  Default 8 x 12; 16 x 6 (CMR_WIDE_GROUP=16)
+// halves the barriers and DMA issue events per block.
+template <int DT, int KS, int WAVES, int CAP, int ABL = 0, int GRP = WIDE_GROUP, int NSTG = WIDE_STAGES>   // ABL: developer ablation (1 no MFMA, 2 no DMA, 3 no barrier)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP P) {
-    static_assert(KS % WIDE_GROUP == 0 && WIDE_GROUP % WAVES == 0, "group/wave geometry");
+    static_assert(KS % GRP == 0 && GRP % WAVES == 0 && GRP / WAVES <= 2, "group/wave geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NQB = WAVES * 32;               // queries per workgroup pass
-    constexpr int GPP = KS / WIDE_GROUP;          // groups per panel
-    constexpr int NST = WIDE_STAGES;
-    constexpr int PPG = WIDE_GROUP / WAVES;       // DMA pieces per wave per group
+    constexpr int GPP = KS / GRP;          // groups per panel
+    constexpr int NST = NSTG;
+    constexpr int PPG = GRP / WAVES;       // DMA pieces per wave per group
     // With two waves per SIMD a wave owns 256 registers: 48 resident fragments (192) + accumulator,
     // read-ahead blocks and epilogue state overflow by a few registers, and hipcc's spill reloads
     // (scratch_load + s_waitcnt vmcnt(0) at the top of every panel) drain the DMA ring — measured
@@ -430,8 +432,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
     constexpr int KLDS = WAVES == 8 ? 4 : 0;
     constexpr int KREG = KS - KLDS;
 
-    v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][WIDE_GROUP][64]
-    int* cnt_all = reinterpret_cast<int*>(smem + NST * WIDE_GROUP * 1024);            // [WAVES][32]
+    v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][GRP][64]
+    int* cnt_all = reinterpret_cast<int*>(smem + NST * GRP * 1024);            // [WAVES][32]
     u64* cstage_all = reinterpret_cast<u64*>(cnt_all + WAVES * 32);                   // [WAVES][CAP+2]
     v4u* qlds = reinterpret_cast<v4u*>(cstage_all + WAVES * (CAP + 2)) + (size_t)wave * KLDS * 64 + lane;   // [WAVES][KLDS][64]
     int* cnt_w = cnt_all + wave * 32;
@@ -481,21 +483,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
         const char* gsrc = reinterpret_cast<const char*>(P.corpus + (size_t)p0 * KS * 64) + (size_t)wave * 1024 + (size_t)lane * 16;
         const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u;
         auto dma_group = [&](const char* g_src, int stage) {
-            const unsigned dst = lds_base + (unsigned)stage * (WIDE_GROUP * 1024u);   // wave-uniform LDS byte address
+            const unsigned dst = lds_base + (unsigned)stage * (GRP * 1024u);   // wave-uniform LDS byte address
             unsigned keep;
             if constexpr (PPG == 1) {
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(g_src), "s"(dst) : "memory");
             } else {
-                const char* g_src2 = g_src + 4096;
+                const char* g_src2 = g_src + WAVES * 1024;          // piece j of wave w is block w + j*WAVES of the group
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                             "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g_src), "v"(g_src2), "s"(dst) : "memory");
+                             "s_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g_src), "v"(g_src2), "s"(dst), "n"(WAVES * 1024) : "memory", "scc");
             }
         };
 #pragma unroll
-        for (int d = 0; d < NST - 1; ++d) dma_group(gsrc + (size_t)d * WIDE_GROUP * 1024, d);
-        gsrc += (size_t)(NST - 1) * WIDE_GROUP * 1024;
+        for (int d = 0; d < NST - 1; ++d) dma_group(gsrc + (size_t)d * GRP * 1024, d);
+        gsrc += (size_t)(NST - 1) * GRP * 1024;
         int st = 0;                                   // stage holding the current group
         // group 0 must be complete before the first reads; from then on the barrier of iteration g
         // validates group g+1, so the reads of group g are issued BEFORE that barrier and the MFMA
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
             for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
             for (int g = 0; g < GPP; ++g) {
-                const v4u* buf = stage_lds + (size_t)st * WIDE_GROUP * 64 + lane;
+                const v4u* buf = stage_lds + (size_t)st * GRP * 64 + lane;
                 constexpr int ADEPTH = WAVES == 8 ? 3 : 4;
                 v4u a[ADEPTH];
 #pragma unroll
@@ -516,16 +518,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
                 if constexpr (ABL == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPG * (NST - 3)) : "memory");
                 else if constexpr (ABL == 2 || ABL == 5) asm volatile("s_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
-                if constexpr (ABL != 2 && ABL != 5) dma_group(gsrc + (size_t)g * WIDE_GROUP * 1024, st == 0 ? NST - 1 : st - 1);
+                if constexpr (ABL != 2 && ABL != 5) dma_group(gsrc + (size_t)g * GRP * 1024, st == 0 ? NST - 1 : st - 1);
 #pragma unroll
-                for (int u = 0; u < WIDE_GROUP; ++u) {
+                for (int u = 0; u < GRP; ++u) {
                     const v4u a_use = a[u % ADEPTH];
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ks = g * WIDE_GROUP + u;
+                    const int ks = g * GRP + u;
                     const v4u b = ks < KREG ? qreg[ks < KREG ? ks : 0] : qlds[(ks < KREG ? 0 : ks - KREG) * 64];
                     if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(a_use), "v"(b));
                     else acc = CmrBlk<DT>::mma(a_use, b, acc);
-                    if (u + ADEPTH < WIDE_GROUP) a[u % ADEPTH] = buf[(u + ADEPTH) * 64];
+                    if (u + ADEPTH < GRP) a[u % ADEPTH] = buf[(u + ADEPTH) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 st = st + 1 == NST ? 0 : st + 1;
@@ -591,6 +593,7 @@ static int wide_waves(int ks) { return ks == 48 ? 8 : 4; }
 size_t cmr_wide_lds_bytes(int ks, int cap) {
     const int waves = wide_waves(ks);
     const int klds = waves == 8 ? 4 : 0;
+    // the corpus ring is 96 KiB for every (group, stages) variant
     return (size_t)WIDE_STAGES * WIDE_GROUP * 1024 + (size_t)waves * 32 * 4 + (size_t)waves * (cap + 2) * 8 +
            (size_t)waves * klds * 1024;
 }
@@ -621,6 +624,12 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipS
         if (abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 4>, 512);
         if (abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 5>, 512);
         if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 6>, 512);
+    }
+    static_assert(WIDE_STAGES * WIDE_GROUP == 6 * 16, "ring variants share one LDS size");
+    if (g.wide_group == 16 && g.ks == 48) {     // experimental: 16-block groups, 6 stages (8-wave variants only)
+#define WCASE16(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 16, 6>, 512);
+        WCASE16(CMR_DT_BF16, 128) WCASE16(CMR_DT_BF16, 256) WCASE16(CMR_DT_F16, 128) WCASE16(CMR_DT_F16, 256)
+#undef WCASE16
     }
 #define WCASE(DT, KSV, WV, CAPV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV) return launch(scan_wide_kernel<DT, KSV, WV, CAPV>, WV * 64);
     WCASE(CMR_DT_BF16, 48, 8, 128) WCASE(CMR_DT_BF16, 48, 8, 256) WCASE(CMR_DT_F16, 48, 8, 128) WCASE(CMR_DT_F16, 48, 8, 256)
