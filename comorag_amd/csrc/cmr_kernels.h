@@ -15,7 +15,7 @@ struct CmrScanGeom {
     int ring;       // register ring depth (8 or 16), ks % ring == 0
     int grid;       // workgroups
     int asm_ring;   // 1: hand-counted inline-asm load ring, 0: compiler-counted loads
-    int wide_group; // wide kernel only: blocks per staged group (0 / 8 = default, 16 = experimental variant)
+    int wide_group; // wide kernel only: 0 / 8 = default; 16 = 16-block groups; -1 = staggered DMA issue (experimental variants)
     size_t lds;     // dynamic LDS bytes
 };
 

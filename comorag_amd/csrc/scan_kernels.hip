@@ -414,7 +414,10 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 
 // GRP blocks per staged group, NSTG groups in the LDS ring (GRP * NSTG = 96 KiB).  Default 8 x 12; 16 x 6 (CMR_WIDE_GROUP=16)
 // halves the barriers and DMA issue events per block.
-template <int DT, int KS, int WAVES, int CAP, int ABL = 0, int GRP = WIDE_GROUP, int NSTG = WIDE_STAGES>   // ABL: developer ablation (1 no MFMA, 2 no DMA, 3 no barrier)
+// STAG = 1 (CMR_WIDE_STAGGER=1, experimental): the DMA of a group is issued by ONE wave per SIMD only — waves w and
+// w+4 share a SIMD, waves 0-3 load the even groups, 4-7 the odd ones, two pieces each — so that in every group each
+// SIMD has a wave that goes from the barrier straight back to its MFMAs.
+template <int DT, int KS, int WAVES, int CAP, int ABL = 0, int GRP = WIDE_GROUP, int NSTG = WIDE_STAGES, int STAG = 0>   // ABL: developer ablation (1 no MFMA, 2 no DMA, 3 no barrier)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP P) {
     static_assert(KS % GRP == 0 && GRP % WAVES == 0 && GRP / WAVES <= 2, "group/wave geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -480,12 +483,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
     __syncthreads();
 
     if (p1 > p0) {
-        const char* gsrc = reinterpret_cast<const char*>(P.corpus + (size_t)p0 * KS * 64) + (size_t)wave * 1024 + (size_t)lane * 16;
-        const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u;
+        static_assert(!STAG || (WAVES == 8 && GRP == 8 && (KS / GRP) % 2 == 0 && NSTG % 2 == 0 && ABL == 0), "stagger geometry");
+        const int half = wave >> 2;                          // 0: loads even groups, 1: odd groups (STAG only)
+        const int wslot = STAG ? (wave & 3) : wave;          // first block of the group this wave moves
+        const char* gsrc = reinterpret_cast<const char*>(P.corpus + (size_t)p0 * KS * 64) + (size_t)wslot * 1024 + (size_t)lane * 16;
+        const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wslot * 1024u;
         auto dma_group = [&](const char* g_src, int stage) {
             const unsigned dst = lds_base + (unsigned)stage * (GRP * 1024u);   // wave-uniform LDS byte address
             unsigned keep;
-            if constexpr (PPG == 1) {
+            if constexpr (STAG) {                            // blocks wslot and wslot + 4 of the group
+                const char* g_src2 = g_src + 4096;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                             "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(g_src), "v"(g_src2), "s"(dst) : "memory", "scc");
+            } else if constexpr (PPG == 1) {
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(g_src), "s"(dst) : "memory");
             } else {
@@ -496,13 +507,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
             }
         };
 #pragma unroll
-        for (int d = 0; d < NST - 1; ++d) dma_group(gsrc + (size_t)d * GRP * 1024, d);
+        for (int d = 0; d < NST - 1; ++d)
+            if (!STAG || half == (d & 1)) dma_group(gsrc + (size_t)d * GRP * 1024, d);
         gsrc += (size_t)(NST - 1) * GRP * 1024;
         int st = 0;                                   // stage holding the current group
         // group 0 must be complete before the first reads; from then on the barrier of iteration g
         // validates group g+1, so the reads of group g are issued BEFORE that barrier and the MFMA
         // chain never drains at a barrier (measured: ~600 of 1100 cycles per group were that bubble)
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 2)) : "memory");
+        if constexpr (STAG) {
+            // half 0 issued groups 0, 2, .. NST-2 (two pieces each): group 0 has landed once <= NST-2 pieces are out.
+            // In iteration g the loaders of group g+1 (== those of group g+NST-1) have issued, after it, the groups
+            // g+3, g+5, .. g+NST-3: NST-4 pieces may stay in flight.
+            if (half == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST - 2) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 2)) : "memory");
+        }
 
         for (int p = p0; p < p1; ++p) {
             f32x16 acc;
@@ -515,10 +535,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP 
                 v4u a[ADEPTH];
 #pragma unroll
                 for (int u = 0; u < ADEPTH; ++u) a[u] = buf[u * 64];
+                if constexpr (STAG) {
+                    const bool loader = half == ((g + 1) & 1);
+                    if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST - 4) : "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    if (loader) dma_group(gsrc + (size_t)g * GRP * 1024, st == 0 ? NST - 1 : st - 1);
+                } else
                 if constexpr (ABL == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPG * (NST - 3)) : "memory");
                 else if constexpr (ABL == 2 || ABL == 5) asm volatile("s_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
-                if constexpr (ABL != 2 && ABL != 5) dma_group(gsrc + (size_t)g * GRP * 1024, st == 0 ? NST - 1 : st - 1);
+                if constexpr (!STAG && ABL != 2 && ABL != 5) dma_group(gsrc + (size_t)g * GRP * 1024, st == 0 ? NST - 1 : st - 1);
 #pragma unroll
                 for (int u = 0; u < GRP; ++u) {
                     const v4u a_use = a[u % ADEPTH];
@@ -626,6 +652,11 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipS
         if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 6>, 512);
     }
     static_assert(WIDE_STAGES * WIDE_GROUP == 6 * 16, "ring variants share one LDS size");
+    if (g.wide_group == -1 && g.ks == 48) {     // experimental: staggered DMA issue (CMR_WIDE_STAGGER=1)
+#define WCASES(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 8, 12, 1>, 512);
+        WCASES(CMR_DT_BF16, 128) WCASES(CMR_DT_BF16, 256) WCASES(CMR_DT_F16, 128) WCASES(CMR_DT_F16, 256)
+#undef WCASES
+    }
     if (g.wide_group == 16 && g.ks == 48) {     // experimental: 16-block groups, 6 stages (8-wave variants only)
 #define WCASE16(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 16, 6>, 512);
         WCASE16(CMR_DT_BF16, 128) WCASE16(CMR_DT_BF16, 256) WCASE16(CMR_DT_F16, 128) WCASE16(CMR_DT_F16, 256)
