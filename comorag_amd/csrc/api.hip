@@ -117,7 +117,7 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
-    int wide_group = 0;      // CMR_WIDE_GROUP=16: 16-block groups x 6 stages; CMR_WIDE_STAGGER=1 (-1): staggered DMA issue (both experimental)
+    int wide_group = 0;      // CMR_WIDE_GROUP=16: 16-block groups x 6 stages; CMR_WIDE_STAGGER=1 (-1): staggered DMA issue; CMR_WIDE_BURST=1 (-2): paired MFMA issue (all experimental)
     int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
     int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves free (-1 = by corpus size, see enqueue_pass)
     std::mutex pipe_mu;
@@ -588,7 +588,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
     idx->sample_div = std::max(2, env_int("CMR_SAMPLE_DIV", 32));
-    idx->wide_group = env_int("CMR_WIDE_STAGGER", 0) ? -1 : env_int("CMR_WIDE_GROUP", 0);
+    idx->wide_group = env_int("CMR_WIDE_BURST", 0) ? -2 : env_int("CMR_WIDE_STAGGER", 0) ? -1 : env_int("CMR_WIDE_GROUP", 0);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);

@@ -1,5 +1,5 @@
 """Round-2 check of the experimental wide-kernel variants (batch 256 in one corpus pass):
-default (8-block groups x 12 stages) vs CMR_WIDE_GROUP=16 vs CMR_WIDE_STAGGER=1.
+default (8-block groups x 12 stages) vs CMR_WIDE_GROUP=16 vs CMR_WIDE_STAGGER=1 vs CMR_WIDE_BURST=1.
 For each: ids/scores must equal the default variant bit for bit; prints step and kernel time."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,8 +14,9 @@ for b in range(0, rows, 250_000):
 q = torch.randn((B, dim), generator=g, device=dev); q = (q / q.norm(dim=1, keepdim=True)).contiguous()
 outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev)) for _ in range(2)]
 ref = None
-for name, env in [("default 8x12", {}), ("group 16x6", {"CMR_WIDE_GROUP": "16"}), ("staggered DMA", {"CMR_WIDE_STAGGER": "1"})]:
-    for kk in ("CMR_WIDE_GROUP", "CMR_WIDE_STAGGER"): os.environ.pop(kk, None)
+for name, env in [("default 8x12", {}), ("group 16x6", {"CMR_WIDE_GROUP": "16"}), ("staggered DMA", {"CMR_WIDE_STAGGER": "1"}),
+                  ("paired MFMAs", {"CMR_WIDE_BURST": "1"})]:
+    for kk in ("CMR_WIDE_GROUP", "CMR_WIDE_STAGGER", "CMR_WIDE_BURST"): os.environ.pop(kk, None)
     os.environ.update(env)
     idx = DenseIndex(dim, "bf16", capacity_hint=rows)
     for x in blocks: idx.append_dev(x)
