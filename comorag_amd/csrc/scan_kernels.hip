@@ -665,7 +665,7 @@ int cmr_wide_queries(int dtype, int dpad) {
 
 hipError_t cmr_launch_scan_wide(const CmrScanGeom& gin, const CmrScanArgs& a, hipStream_t s) {
     CmrScanGeom g = gin;
-    if (g.wide_group == -2 && !(g.ks == 48 && g.cap == 128)) g.wide_group = 0;      // variant not built for this shape
+    if (g.wide_group < 0 && g.ks != 48) g.wide_group = 0;      // experimental variants exist for the 8-wave (768-d) shape only
     const ScanP p = to_p(g, a);
     const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap, g.wide_group);
     auto launch = [&](auto kern, int threads) -> hipError_t {
@@ -684,9 +684,10 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& gin, const CmrScanArgs& a, hi
         if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 6>, 512);
     }
     static_assert(WIDE_STAGES * WIDE_GROUP == 6 * 16, "ring variants share one LDS size");
-    if (g.wide_group == -2 && g.ks == 48 && g.cap == 128) {     // experimental: paired MFMA issue (CMR_WIDE_BURST=1), 16-block groups
-        if (g.dtype == CMR_DT_BF16) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 0, 16, 6, 0, 2>, 512);
-        if (g.dtype == CMR_DT_F16) return launch(scan_wide_kernel<CMR_DT_F16, 48, 8, 128, 0, 16, 6, 0, 2>, 512);
+    if (g.wide_group == -2 && g.ks == 48) {     // experimental: paired MFMA issue (CMR_WIDE_BURST=1), 16-block groups
+#define WCASEB(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 16, 6, 0, 2>, 512);
+        WCASEB(CMR_DT_BF16, 128) WCASEB(CMR_DT_BF16, 256) WCASEB(CMR_DT_F16, 128) WCASEB(CMR_DT_F16, 256)
+#undef WCASEB
     }
     if (g.wide_group == -1 && g.ks == 48) {     // experimental: staggered DMA issue (CMR_WIDE_STAGGER=1)
 #define WCASES(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 8, 12, 1>, 512);
