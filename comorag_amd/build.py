@@ -108,6 +108,58 @@ def audit_ring(asm_text: str) -> dict:
     return result
 
 
+_WIDE_RE = re.compile(r"^_Z16scan_wide_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
+
+
+def audit_wide(asm_text: str) -> dict:
+    """The wide kernel keeps 384 registers of query fragments resident and issues its MFMAs as inline asm (hipcc pads
+    no hazards around them).  Per scan_wide_kernel<DT,KS,NT,CAP,NST,KLDS> require: no scratch traffic at all (a spill
+    reload inside the panel loop would drain the hand-counted DMA ring), no v_accvgpr_write and at most 16*NT
+    v_accvgpr_read (the epilogue's reads of the accumulators: anything more means fragments are being shuttled
+    between the register files in front of the MFMAs), and no compiler VALU write of an MFMA A/B operand register
+    in the three instructions before an asm MFMA (VALU write -> MFMA read needs wait states hipcc does not insert).
+    Returns {(dt,ks,nt,cap): problem string or ''}."""
+    result = {}
+    lines = asm_text.split("\n")
+    i = 0
+    while i < len(lines):
+        m = _WIDE_RE.match(lines[i])
+        if not m:
+            i += 1
+            continue
+        dt, ks, nt, cap, nst, klds = (int(x) for x in m.groups())
+        j = i + 1
+        body = []
+        while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+            body.append(lines[j].strip())
+            j += 1
+        i = j
+        code = [l.split(";")[0].strip() for l in body if l and not l.startswith(";") and not l.startswith(".")]
+        code = [c for c in code if c]
+        problems = []
+        if any(c.startswith("scratch_") for c in code):
+            problems.append("scratch traffic")
+        if any(c.startswith("v_accvgpr_write") for c in code):
+            problems.append("v_accvgpr_write")
+        n_read = sum(c.startswith("v_accvgpr_read") for c in code)
+        if n_read > 16 * nt:
+            problems.append(f"{n_read} v_accvgpr_read > {16 * nt}")
+        n_mfma = 0
+        for n, c in enumerate(code):
+            if not c.startswith("v_mfma"):
+                continue
+            n_mfma += 1
+            ops = c.split(",")
+            src = _regs(ops[1]) | _regs(ops[2])
+            for prev in code[max(0, n - 3):n]:
+                if prev.startswith("v_") and not prev.startswith("v_mfma") and not prev.startswith("v_cmp") and _regs(prev.split(",")[0]) & src:
+                    problems.append(f"VALU write of an MFMA operand right before it: '{prev}' -> '{c}'")
+        if n_mfma < ks * nt:
+            problems.append(f"only {n_mfma} MFMAs found")
+        result[(dt, ks, nt, cap)] = "; ".join(problems)
+    return result
+
+
 def _run(cmd, cwd=None):
     r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -144,6 +196,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
         audit = audit_ring(open(asm_file).read())
         if not audit:       # the mangled-name pattern no longer matches: every variant would silently lose its ring
             raise RuntimeError("ISA audit found no scan_kernel<..., ASMRING=1> in the assembly; update _KERNEL_RE")
+        wide = audit_wide(open(asm_file).read())
+        if not wide:
+            raise RuntimeError("ISA audit found no scan_wide_kernel in the assembly; update _WIDE_RE")
+        bad = {k: v for k, v in wide.items() if v}
+        if bad:             # there is no second implementation to fall back to: refuse to ship a wide kernel that spills
+            raise RuntimeError(f"wide-kernel ISA audit failed: {bad}")
         # 2. audit table
         rows = ",\n".join(f"    {{{dt}, {nqt}, {cap}, {ring}, {mode}, {1 if ok else 0}}}"
                           for (dt, nqt, cap, ring, mode), ok in sorted(audit.items()))
@@ -169,7 +227,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(o)
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
     n_ok = sum(audit.values())
-    info = {"hash": want, "arch": ARCH, "asm_ring_variants": len(audit), "asm_ring_safe": n_ok,
+    info = {"hash": want, "arch": ARCH, "wide_variants_audited": len(wide), "asm_ring_variants": len(audit), "asm_ring_safe": n_ok,
             "unsafe": [list(k) for k, v in sorted(audit.items()) if not v]}
     json.dump(info, open(STAMP, "w"), indent=1)
     if verbose:

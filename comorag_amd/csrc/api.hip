@@ -24,6 +24,7 @@
 #define CMR_CORPUS_SLACK (128 * 1024)
 
 bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring);  // ring_audit.cpp (generated at build)
+static const long long kMaxMergeLists = 4096;                    // merge_query_kernel: W <= 16 * MERGE_THREADS
 
 namespace {
 
@@ -117,7 +118,6 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
-    int wide_group = 0;      // CMR_WIDE_GROUP=16: 16-block groups x 6 stages; CMR_WIDE_STAGGER=1 (-1): staggered DMA issue; CMR_WIDE_BURST=1 (-2): paired MFMA issue (all experimental)
     int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
     int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves free (-1 = by corpus size, see enqueue_pass)
     std::mutex pipe_mu;
@@ -197,7 +197,6 @@ int make_geom(cmr_index* idx, int nq, int k, bool topk, CmrScanGeom* g) {
     if (max_nqt == 0) return fail(CMR_ERR_UNSUPPORTED, "dim %d too large for the LDS-resident query tile (dtype %d)", idx->dim, idx->dtype);
     g->dtype = idx->dtype;
     g->dpad = idx->dpad;
-    g->wide_group = idx->wide_group;
     g->nqt = (nq > 32 && max_nqt >= 2) ? 2 : 1;
     g->cap = (topk && k > 32) ? 256 : 128;
     const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
@@ -283,34 +282,55 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     // what changes is that only ~S_{i+1}*k/S_i scores per query ever reach the candidate lists
     // (instead of k*ln(rows/k) per wave and query), which keeps every merge at a few thousand keys.
     //   S0 = max(512, 32k) rows, S1 = clamp(N/32, 8*S0, 128*S0) rows (only when N >= 128 Ki rows)
+    // Narrow kernel: one sampled panel per wave = one candidate list per panel, and merge_query_kernel takes at
+    // most 4096 lists, so S1 is capped there (k > 32 on multi-million-row shards would otherwise overrun it).
+    // Wide kernel: the sampling workgroups split the sampled panels among them (one list per workgroup and query).
     long long level_panels[2] = {0, 0};
     int n_levels = 0;
     if (!idx->no_sample && npanels >= 256) {
         const long long s0 = std::max<long long>(16, k);                       // panels
         level_panels[n_levels++] = s0;
         if (npanels >= 4096) {
-            const long long s1 = std::min<long long>(std::max<long long>(npanels / idx->sample_div, 8 * s0), 128 * s0);
+            long long s1 = std::min<long long>(std::max<long long>(npanels / idx->sample_div, 8 * s0), 128 * s0);
+            if (!wide) s1 = std::min<long long>(s1, kMaxMergeLists);
             if (s1 < npanels / 2) level_panels[n_levels++] = s1;
         }
     }
     const long long max_sample = std::max(level_panels[0], level_panels[1]);
-    const int Ws = max_sample ? (int)((max_sample + lists_per_wg - 1) / lists_per_wg) * lists_per_wg : 0;
+    const bool pipelined = sp != sm;
     if (reserve_cus < 0) {
-        // Pipelined mode, reserve chosen by size: the next batch's pre-phase has to fit under this scan (~6 TB/s).
-        // It is ~200 us of dependent small kernels plus ~200 us per round of its largest sampling pass on the
-        // reserved CUs (every sampling workgroup stages the 96 KiB query tile and its loads crawl while the scan
-        // saturates HBM: at 10 M rows 320 workgroups on 26 CUs took 2.3 ms and overran the scan by 90 us, on 34
-        // CUs they fit).  Reserved CUs cost the scan bandwidth only at short scans (64 of 256: ~3 % at 1 M rows,
-        // nothing measurable at 10 M).  Measured at 1 / 1.25 / 2.5 / 5 / 10 M rows x 768 bf16.
-        const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
-        const long long rounds = (long long)((0.7 * scan_us - 200.0) / 200.0);
-        const long long wgs = std::max<long long>(1, Ws / lists_per_wg);
-        reserve_cus = rounds >= 1 ? (int)std::min<long long>(64, std::max<long long>(8, (wgs + rounds - 1) / rounds)) : 64;
-        if (!Ws) reserve_cus = 0;
+        if (!max_sample) reserve_cus = 0;
+        else if (wide) {
+            // Pipelined mode, wide kernel: a sampling workgroup owns a CU (512 registers per wave), so the next batch's
+            // pre-phase runs on reserved CUs: ~120 us of dependent small kernels + S1 panels at ~2.5 us each (MFMA-paced,
+            // slowed by the saturating main scan) have to fit under ~60 % of this scan.  The main scan is HBM-bound with
+            // the matrix pipe ~65 % busy, so a few CUs are cheap; 1/4 of the chip is the cap.
+            const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
+            const double room = std::max(0.6 * scan_us - 120.0, 25.0);
+            reserve_cus = (int)std::min<double>(idx->n_cu / 4, std::max(8.0, std::ceil((double)max_sample * 2.5 / room)));
+        } else {
+            // Pipelined mode, reserve chosen by size: the next batch's pre-phase has to fit under this scan (~6 TB/s).
+            // It is ~200 us of dependent small kernels plus ~200 us per round of its largest sampling pass on the
+            // reserved CUs (every sampling workgroup stages the 96 KiB query tile and its loads crawl while the scan
+            // saturates HBM: at 10 M rows 320 workgroups on 26 CUs took 2.3 ms and overran the scan by 90 us, on 34
+            // CUs they fit).  Reserved CUs cost the scan bandwidth only at short scans (64 of 256: ~3 % at 1 M rows,
+            // nothing measurable at 10 M).  Measured at 1 / 1.25 / 2.5 / 5 / 10 M rows x 768 bf16.
+            const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
+            const long long rounds = (long long)((0.7 * scan_us - 200.0) / 200.0);
+            const long long wgs = std::max<long long>(1, (max_sample + lists_per_wg - 1) / lists_per_wg);
+            reserve_cus = rounds >= 1 ? (int)std::min<long long>(64, std::max<long long>(8, (wgs + rounds - 1) / rounds)) : 64;
+        }
     }
+    // workgroups of a sampling pass over spn panels, and candidate lists it produces
+    auto sample_grid = [&](long long spn) -> int {
+        if (!wide) return (int)((spn + lists_per_wg - 1) / lists_per_wg);
+        const int cap_wgs = pipelined && reserve_cus > 0 ? reserve_cus : idx->n_cu;
+        return (int)std::min<long long>(spn, cap_wgs);
+    };
+    const int Ws = max_sample ? std::max(sample_grid(level_panels[0]), n_levels > 1 ? sample_grid(level_panels[1]) : 0) * lists_per_wg : 0;
     int NQ, W, tiles;
     if (wide) {
-        // register-resident queries: 32 per wave, 8 or 4 waves per workgroup, one list row per
+        // register-resident queries: 4 waves x 2 (768-d) or 1 (1024-d) tiles of 32, one list row per
         // (workgroup, query); one workgroup per CU
         const int nqb = cmr_wide_queries(idx->dtype, idx->dpad);
         g.nqt = 1;
@@ -340,9 +360,9 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     a.nq = nqp;
     for (int lv = 0; lv < n_levels; ++lv) {
         const long long spn = level_panels[lv];
-        const int Wl = (int)((spn + lists_per_wg - 1) / lists_per_wg) * lists_per_wg;
         CmrScanGeom gs = g;
-        gs.grid = Wl / lists_per_wg;
+        gs.grid = sample_grid(spn);
+        const int Wl = gs.grid * lists_per_wg;
         CmrScanArgs as = a;
         as.lists = (u64*)ws->s_lists.p; as.cnt = (int*)ws->s_cnt.p; as.mm = (float2*)ws->s_mm.p;
         as.sample_waves = (int)spn; as.sample_stride = (int)(npanels / spn);
@@ -446,9 +466,8 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
             // the scan stream itself costs ~10 us between two main scans.
             HIP_TRY(hipStreamWaitEvent(P.sp, sl->scan_done, 0));
         }
-        // the wide kernel is MFMA-bound, not HBM-bound: it keeps every CU
         int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
-                              wide ? 0 : idx->reserve_cus,
+                              idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
@@ -588,7 +607,6 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
     idx->sample_div = std::max(2, env_int("CMR_SAMPLE_DIV", 32));
-    idx->wide_group = env_int("CMR_WIDE_BURST", 0) ? -2 : env_int("CMR_WIDE_STAGGER", 0) ? -1 : env_int("CMR_WIDE_GROUP", 0);
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);

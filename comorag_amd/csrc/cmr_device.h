@@ -54,18 +54,44 @@ __device__ __forceinline__ float cmr_h2f(unsigned short h) { return (float)__bui
 //   16-bit dtypes: 32 rows x 16 k.  lane l holds row (l & 31), k = 16*ks + 8*(l >> 5) + [0,8)
 //   fp32         : 32 rows x  8 k.  lane l holds row (l & 31), k =  8*ks + 2*s + (l >> 5), s = 0..3
 // (any k permutation is fine for a dot product as long as corpus and query blocks agree).
+// The wide kernel issues its MFMAs as inline asm so that the register FILE of every operand is fixed by the
+// constraint (v = VGPR half, a = AGPR half of the unified 512-entry file): left to hipcc, B-operands that live in
+// AGPRs are shuttled through v_accvgpr_read in front of every MFMA as soon as the loop body contains a branch.
+// hipcc pads no hazards around these statements (guide §5.7 item 2): the first MFMA of a chain takes the literal 0
+// as C (no VALU-written accumulator), chains accumulate in place (0 wait states), and the caller ends a chain
+// with cmr_mfma_drain() before any VALU / v_accvgpr_read touches the accumulators.
+//   AB: 0 = B in VGPRs, 1 = B in AGPRs;  FIRST: C = 0
+#define CMR_MFMA_ASM(MNEMONIC)                                                                                      \
+    static __device__ __forceinline__ void mma_asm(int ab, bool first, f32x16& c, const v4u& a, const v4u& b) {      \
+        /* ab / first are constants after unrolling: exactly one statement survives */                               \
+        if (first) {                                                                                                 \
+            if (ab) asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&a"(c) : "v"(a), "a"(b));                              \
+            else asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&a"(c) : "v"(a), "v"(b));                                 \
+        } else {                                                                                                     \
+            if (ab) asm volatile(MNEMONIC " %0, %1, %2, %0" : "+a"(c) : "v"(a), "a"(b));                              \
+            else asm volatile(MNEMONIC " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));                                 \
+        }                                                                                                            \
+    }
+// 8-pass XDL result -> any non-MFMA reader: 12 wait states (guide §5.7 item 2); s_nop 15 = 16
+template <int NT> __device__ __forceinline__ void cmr_mfma_drain(f32x16 (&acc)[NT]) {
+    if constexpr (NT == 1) asm volatile("s_nop 15" : "+a"(acc[0]));
+    else asm volatile("s_nop 15" : "+a"(acc[0]), "+a"(acc[1]));
+}
+
 template <int DT> struct CmrBlk;
 template <> struct CmrBlk<CMR_DT_BF16> {
     static constexpr int K = 16;
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    CMR_MFMA_ASM("v_mfma_f32_32x32x16_bf16")
 };
 template <> struct CmrBlk<CMR_DT_F16> {
     static constexpr int K = 16;
     static __device__ __forceinline__ f32x16 mma(v4u a, v4u b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
+    CMR_MFMA_ASM("v_mfma_f32_32x32x16_f16")
 };
 template <> struct CmrBlk<CMR_DT_F32> {
     static constexpr int K = 8;

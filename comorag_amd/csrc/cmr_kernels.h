@@ -15,7 +15,6 @@ struct CmrScanGeom {
     int ring;       // register ring depth (8 or 16), ks % ring == 0
     int grid;       // workgroups
     int asm_ring;   // 1: hand-counted inline-asm load ring, 0: compiler-counted loads
-    int wide_group; // wide kernel only: 0 / 8 = default; 16 = 16-block groups; -1 = staggered DMA issue; -2 = paired MFMA issue (experimental variants)
     size_t lds;     // dynamic LDS bytes
 };
 
@@ -46,10 +45,11 @@ struct CmrScanArgs {
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
 hipError_t cmr_launch_scan_scores(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
-// wide-batch (register-resident queries) top-k scan: 32 queries per wave, 8 (768-d) or 4 (1024-d) waves
+// wide-batch (register-resident queries) top-k scan: 4 waves x 2 (768-d) or 1 (1024-d) tiles of 32 queries;
+// in sampling mode (sample_waves > 0) the grid's workgroups split the sample_waves strided panels among them
 hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
 int cmr_wide_queries(int dtype, int dpad);      // queries per pass of the wide kernel (0 = unavailable)
-size_t cmr_wide_lds_bytes(int ks, int cap, int variant);
+size_t cmr_wide_lds_bytes(int ks, int cap);
 
 // queries fp32 [nq, dim] (device) -> fragment-ordered blocks of the index dtype, zero padded
 hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt,

@@ -127,16 +127,6 @@ __device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0
     if (need) topk_compact<CAP>(need, k, tau_key, tau_f, cnt_t, list_t, stage, lane);
 }
 
-// Out-of-line compaction for the wide kernel: its resident query registers must not be squeezed by
-// the compaction's temporaries, and a call's callee-saved spill/reload (with its s_waitcnt vmcnt(0),
-// which drains the DMA ring) must stay off the common slow path — so only the rare compaction is a
-// call; the pushes are inline.
-template <int CAP>
-__device__ __attribute__((noinline)) void topk_compact_call(u64 need, int k, u64* tau_key, float* tau_f, int* cnt_t, u64* list_t,
-                                                            u64* stage, int lane) {
-    topk_compact<CAP>(need, k, *tau_key, *tau_f, cnt_t, list_t, stage, lane);
-}
-
 template <int DT, int NQT, int CAP, int R, int MODE, int ASMRING>
 __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -388,274 +378,331 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 
 // ------------------------------------------------------------------------------------------
 // Wide-batch scan: up to 256 queries in ONE pass over the corpus (BASELINE config 3's batch-256).
-// The LDS-resident query tile of scan_kernel tops out at 64 queries (96 KiB); here the queries
-// live in REGISTERS: every wave keeps the MFMA B-operands of ITS 32 queries resident (KS blocks x
-// 4 VGPRs = 192 registers at 768-d), a workgroup of WAVES waves covers WAVES*32 queries (8 waves,
-// two per SIMD, 256 queries at 768-d; 4 waves, 128 queries at 1024-d where a tile needs 256
-// registers).  All waves consume the same corpus blocks: the stream goes HBM -> LDS by LDS-DMA
-// (global_load_lds_dwordx4: one wave moves one 1-KiB block, lane-linear — exactly the block layout)
-// into a ring of NST groups of 8 blocks, NST-1 groups (88 KiB) in flight per workgroup and no VGPR
-// spent on it; every wave reads each block back (ds_read_b128, one block ahead) and issues one
-// MFMA per block.  HBM traffic stays 1x while the MFMA work is 4x that of the 64-query kernel
-// (75 % of the MFMA pipe at the HBM rate for 768-d bf16: still HBM-bound on paper).
-//   per group g:  first ds_reads of group g        (validated by the previous iteration's barrier)
-//                 s_waitcnt vmcnt(PPG*(NST-3))   my DMA pieces of group g+1 have landed
-//                 s_barrier                        everybody's have; everybody left group g-1
-//                 DMA group g+NST-1 -> stage (g-1) mod NST
-//                 8 x (MFMA + ds_read_b128 three blocks ahead) from stage g mod NST
-// Counted waits + raw s_barrier (__syncthreads() would drain the DMA queue, guide §5); the DMAs are
-// inline asm (§5.7 recipe: M0 = LDS destination, saved/restored inside the statement) so hipcc
-// neither counts them nor drains them before LDS reads.  The tail over-reads NST-1 groups past the
-// range: CMR_CORPUS_SLACK covers it.  The top-k epilogue, candidate lists and thresholds are the
-// per-wave ones of scan_kernel; list / counter rows are laid out [workgroup][WAVES*32 queries] so
-// merge_query_kernel consumes them with W = gridDim.x.
-#define WIDE_GROUP 8      // blocks per staged group
-#define WIDE_STAGES 12    // LDS ring depth in groups (96 KiB)
+// The LDS-resident query tile of scan_kernel tops out at 64 queries (96 KiB); here the queries live
+// in REGISTERS.  A workgroup is 4 waves, ONE per SIMD, so a wave owns the SIMD's whole 512-entry
+// register file (VGPR + AGPR, unified on gfx950; MFMA B-operands may be AGPRs): it keeps the MFMA
+// B-operands of NT = 2 query tiles resident (2 x 48 blocks x 4 registers = 384 at 768-d; NT = 1 at
+// 1024-d) and 4 waves cover 4*NT*32 = 256 (128) queries.
+//   * All waves consume the same corpus blocks: HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, one
+//     wave-instruction moves one 1-KiB block, lane-linear = exactly the block layout) into a ring of
+//     NSTG groups of GRP blocks; NSTG-1 groups stay in flight per workgroup and no VGPR is spent on
+//     the stream.  Every wave reads each block back ONCE (ds_read_b128, ADEPTH blocks ahead, the
+//     read-ahead runs across group and panel boundaries) and feeds it to NT MFMAs, one per tile:
+//     two independent accumulator chains interleave, so no MFMA waits for its predecessor, while
+//     each query's own fp32 chain keeps the k order of scan_kernel (bit-identical scores).
+//   * per group g:  s_waitcnt vmcnt(PPG*(NSTG-3))   my DMA pieces of group g+1 have landed
+//                   s_barrier                        everybody's have; everybody left group g-1
+//                   GRP x { NT MFMAs, ds_read_b128 ADEPTH blocks ahead },
+//                   with the PPG DMA pieces of group g+NSTG-1 -> stage (g-1) mod NSTG spread between them
+//     Counted waits + raw s_barrier (__syncthreads() would drain the DMA queue, guide §5); the DMAs
+//     are inline asm (§5.7 recipe: M0 = LDS destination, saved/restored inside the statement) with a
+//     wave-uniform SGPR base, so hipcc neither counts them nor drains them before LDS reads.
+//   * Budget per CU and 32-row panel at 768-d: 4 SIMDs x 96 MFMAs x 32 cycles = 3072 cycles, 192 KiB
+//     of ds_read_b128 = 768 cycles, 48 KiB of HBM = ~4900 cycles at the achievable rate: HBM-bound with
+//     the matrix pipe ~63 % busy.
+//   * A workgroup scans the panels {s * pstride : s in [s0, s1)} — pstride = 1 for the main pass, the
+//     sample stride for a sampling pass (a sampling workgroup takes MANY strided panels: loading the
+//     384 KiB of query fragments is the fixed cost of a workgroup).  The prefetch cursor is clamped to
+//     the workgroup's last group, so nothing is read outside [first, last] panel of the range.
+// The top-k epilogue, candidate lists and thresholds are the per-wave ones of scan_kernel; list /
+// counter rows are laid out [workgroup][4*NT*32 queries] so merge_query_kernel consumes them with
+// W = gridDim.x.
+#define WIDE_WAVES 4
+#define WIDE_GROUP 16     // blocks per staged group
+#define WIDE_ADEPTH 4     // blocks read ahead from LDS per wave
 
-// GRP blocks per staged group, NSTG groups in the LDS ring (GRP * NSTG = 96 KiB).  Default 8 x 12; 16 x 6 (CMR_WIDE_GROUP=16)
-// halves the barriers and DMA issue events per block.
-// BURST = 2 (CMR_WIDE_BURST=1, experimental): the MFMAs are issued in adjacent PAIRS with one operand wait in front
-// of the pair.  Every MFMA of a panel accumulates into the same 16 registers; an instruction between two such MFMAs
-// (here: the s_waitcnt + ds_read_b128 of the operand stream) costs the forwarding window, ~43 cycles per MFMA
-// (MI355X_MICROARCH.md constants table) — per pair instead of per MFMA with BURST = 2.  The chain order, hence every
-// score bit, is unchanged.
-// STAG = 1 (CMR_WIDE_STAGGER=1, experimental): the DMA of a group is issued by ONE wave per SIMD only — waves w and
-// w+4 share a SIMD, waves 0-3 load the even groups, 4-7 the odd ones, two pieces each — so that in every group each
-// SIMD has a wave that goes from the barrier straight back to its MFMAs.
-template <int DT, int KS, int WAVES, int CAP, int ABL = 0, int GRP = WIDE_GROUP, int NSTG = WIDE_STAGES, int STAG = 0, int BURST = 1>   // ABL: developer ablation (1 no MFMA, 2 no DMA, 3 no barrier)
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void scan_wide_kernel(ScanP P) {
-    static_assert(KS % GRP == 0 && GRP % WAVES == 0 && GRP / WAVES <= 2, "group/wave geometry");
+// Epilogue pieces of the wide kernel.  The wave's register file is full of query fragments, and hipcc's allocator
+// spills the values with the longest live range first — the fragments — whenever ANY block of the loop needs more
+// registers than are free, so the epilogue is written to need a handful: 32-bit row arithmetic, accumulator values
+// taken four at a time, and the pushes kept sequential (sched_barrier) instead of sixteen in flight.
+__device__ __forceinline__ float wide_max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));   // no canonicalising v_max(x, x) per asm-produced input
+    return d;
+}
+__device__ __forceinline__ float wide_min3(float a, float b, float c) {
+    float d;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// panel max (returned) and running min / max of one tile's 16 scores per lane
+__device__ __forceinline__ float wide_minmax(const f32x16& acc, float& rmin, float& rmax) {
+    float mx = -__builtin_inff(), mn = rmin;
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+        mx = wide_max3(mx, acc[r], acc[r + 1]);
+        mn = wide_min3(mn, acc[r], acc[r + 1]);
+        mx = wide_max3(mx, acc[r + 2], acc[r + 3]);
+        mn = wide_min3(mn, acc[r + 2], acc[r + 3]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    rmin = mn;
+    rmax = wide_max3(rmax, mx, mx);
+    return mx;
+}
+// the same for the corpus' last, partial panel: rows >= nvalid are padding
+__device__ __forceinline__ float wide_minmax_partial(const f32x16& acc, int nvalid, int lane, float& rmin, float& rmax) {
+    float mx = -__builtin_inff(), mn = rmin;
+    int lim = nvalid - 4 * (lane >> 5);          // accumulator register r holds panel row crow(r) + 4 * (lane >> 5)
+    asm volatile("" : "+v"(lim));                 // not loop-invariant for hipcc: stays inside the (cold) caller branch
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = (r & 3) + 8 * (r >> 2) < lim;
+        const float v = acc[r];
+        mx = wide_max3(mx, ok ? v : -__builtin_inff(), mx);
+        mn = wide_min3(mn, ok ? v : __builtin_inff(), mn);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    rmin = mn;
+    rmax = wide_max3(rmax, mx, mx);
+    return mx;
+}
+// topk_push with 32-bit rows, one value at a time.  Everything derived from the lane id is made opaque here: hipcc
+// would otherwise hoist sixteen per-register row offsets and the list pointers out of the panel loop, as
+// loop-invariant values that then live across the whole scan.
+template <int CAP>
+__device__ __forceinline__ u64 wide_push(const f32x16& acc, unsigned row0, int nvalid, u64 tau_key, float tau_f, int* cnt_t, u64* list_t,
+                                         int lane) {
+    int ql = lane & 31;
+    int hrow = 4 * (lane >> 5);
+    asm volatile("" : "+v"(ql), "+v"(hrow));
+    const unsigned rbase = row0 + (unsigned)hrow;
+    const int lim = nvalid - hrow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        // float pre-filter first (one compare; a whole wave usually skips the register): the key compare decides ties
+        if (v >= tau_f) {
+            const int cr = (r & 3) + 8 * (r >> 2);
+            const u64 key = cmr_make_key(v, rbase + (unsigned)cr);
+            if (cr < lim && key > tau_key) {
+                const int slot = atomicAdd(&cnt_t[ql], 1);  // ds_add_rtn_u32; <= 32 pushes per query per panel
+                list_t[(size_t)ql * CAP + slot] = key;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // as topk_push: counters current, pushed keys fenced by the compaction
+    const int c = __hip_atomic_load(&cnt_t[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __ballot(c > CAP - 32) & 0xFFFFFFFFull;
+}
+// topk_compact for the wide kernel: the same rank-by-counting compaction, but every list element goes through the
+// LDS stage instead of being held in registers, and no loop is unrolled — about a dozen registers in all.  (An
+// out-of-line call is no way out: the callee's clobber set keeps the caller's long-lived fragments out of v0..v65.)
+template <int CAP>
+__device__ __forceinline__ void wide_compact(u64 need, int k, u64& tau_key, float& tau_f, int* cnt_t, u64* list_t, u64* stage, int lane) {
+    int ql = lane & 31;
+    asm volatile("" : "+v"(ql), "+v"(lane));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // pushes landed (same-CU L1 is coherent)
+    while (need) {
+        const int j = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int n = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnt_t[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        u64* L = list_t + (size_t)j * CAP;
+#pragma nounroll
+        for (int i = lane; i < n; i += 64) stage[i] = L[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma nounroll
+        for (int i = lane; i < n; i += 64) {
+            const u64 e = stage[i];
+            int rk = 0;
+#pragma nounroll
+            for (int jj = 0; jj < n; ++jj) rk += (stage[jj] > e) ? 1 : 0;     // uniform address: LDS broadcast
+            if (rk < k) L[rk] = e;                 // keys are unique: ranks are a permutation
+            if (rk == k - 1) stage[CAP] = e;
+        }
+        if (lane == 0) __hip_atomic_store(&cnt_t[j], n < k ? n : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (n >= k) {
+            const u64 nt = stage[CAP];
+            if (ql == j) { tau_key = nt; tau_f = cmr_key_score(nt); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+}
+
+template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS>
+__global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) {
+    constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = WIDE_ADEPTH;
+    static_assert(KS % GRP == 0 && GRP % WIDE_WAVES == 0 && GRP % ADEPTH == 0 && NST >= 4, "group geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NQB = WAVES * 32;               // queries per workgroup pass
-    constexpr int GPP = KS / GRP;          // groups per panel
-    constexpr int NST = NSTG;
-    constexpr int PPG = GRP / WAVES;       // DMA pieces per wave per group
-    // With two waves per SIMD a wave owns 256 registers: 48 resident fragments (192) + accumulator,
-    // read-ahead blocks and epilogue state overflow by a few registers, and hipcc's spill reloads
-    // (scratch_load + s_waitcnt vmcnt(0) at the top of every panel) drain the DMA ring — measured
-    // 1.3 of 4.7 ms.  The last KLDS k-steps of the tile are therefore served from LDS.
-    static_assert(BURST == 1 || (BURST == 2 && WAVES == 8 && GRP % 2 == 0 && ABL == 0), "burst geometry");
-    constexpr int KLDS = WAVES == 8 ? 4 : 0;
-    constexpr int KREG = KS - KLDS;
+    constexpr int NQB = WIDE_WAVES * NT * 32;     // queries per workgroup pass
+    constexpr int GPP = KS / GRP;                 // groups per panel
+    constexpr int PPG = GRP / WIDE_WAVES;         // DMA pieces per wave per group
+    constexpr int DSTEP = GRP / PPG;              // a piece is issued every DSTEP blocks
+    constexpr int KREG = KS - KLDS;               // k-steps of a tile resident in registers; the last KLDS sit in LDS
 
     v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][GRP][64]
-    int* cnt_all = reinterpret_cast<int*>(smem + NST * GRP * 1024);            // [WAVES][32]
-    u64* cstage_all = reinterpret_cast<u64*>(cnt_all + WAVES * 32);                   // [WAVES][CAP+2]
-    v4u* qlds = reinterpret_cast<v4u*>(cstage_all + WAVES * (CAP + 2)) + (size_t)wave * KLDS * 64 + lane;   // [WAVES][KLDS][64]
-    int* cnt_w = cnt_all + wave * 32;
+    int* cnt_all = reinterpret_cast<int*>(smem + NST * GRP * 1024);                   // [NQB]
+    u64* cstage_all = reinterpret_cast<u64*>(cnt_all + NQB);                          // [WAVES][CAP+2]
+    v4u* qlds = reinterpret_cast<v4u*>(cstage_all + WIDE_WAVES * (CAP + 2)) + (size_t)wave * NT * KLDS * 64 + lane;   // [WAVES][NT][KLDS][64]
+    int* cnt_w = cnt_all + wave * NT * 32;
     u64* cstage = cstage_all + wave * (CAP + 2);
-    for (int i = tid; i < WAVES * 32; i += WAVES * 64) cnt_all[i] = 0;
+    for (int i = tid; i < NQB; i += WIDE_WAVES * 64) cnt_all[i] = 0;
 
     // this wave's query fragments -> registers (static indices everywhere below)
-    v4u qreg[KREG];
+    v4u qreg[NT][KREG];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const v4u v = P.qfrag[((size_t)wave * KS + ks) * 64 + lane];
-        if (ks < KREG) qreg[ks < KREG ? ks : 0] = v;
-        else qlds[(ks - KREG) * 64] = v;                 // written and read by the same lane only
-    }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v4u v = P.qfrag[((size_t)(wave * NT + t) * KS + ks) * 64 + lane];
+            if (ks < KREG) qreg[t][ks < KREG ? ks : 0] = v;
+            else qlds[(t * KLDS + (ks - KREG)) * 64] = v;        // written and read by the same lane only
+        }
     // Make hipcc retire every query-fragment load HERE: left alone it defers each wait to the
     // fragment's first use inside the panel loop, where stale low-count s_waitcnt vmcnt(N) would
     // drain the hand-counted DMA ring on every iteration.
-#pragma unroll
-    for (int ks = 0; ks < KREG; ++ks) asm volatile("" ::"v"(qreg[ks]));
+    // (An explicit wait rather than an asm "v" pin of every fragment: a "v" constraint would force the fragments into
+    // the VGPR half of the file, and hipcc then shuttles them through v_accvgpr_read in front of every MFMA.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
 
+    // panels of this workgroup: s in [s0, s1) of the (sampled) panel sequence, actual panel s * pstride
     const int nb = gridDim.x;
-    int p0, p1;
-    if (P.sample_waves > 0) {   // sampling pass: workgroup b scans the single strided panel b*stride
-        p0 = blockIdx.x * P.sample_stride;
-        p1 = (int)blockIdx.x < P.sample_waves ? p0 + 1 : p0;
-    } else {
-        p0 = (int)(((long long)blockIdx.x * P.npanels) / nb);
-        p1 = (int)(((long long)(blockIdx.x + 1) * P.npanels) / nb);
-    }
+    const int pstride = P.sample_waves > 0 ? P.sample_stride : 1;
+    const int S = P.sample_waves > 0 ? P.sample_waves : P.npanels;
+    const int s0 = (int)(((long long)blockIdx.x * S) / nb);
+    const int s1 = (int)(((long long)(blockIdx.x + 1) * S) / nb);
 
-    float rmin = __builtin_inff(), rmax = -__builtin_inff(), tau_f = -__builtin_inff();
-    u64 tau_key = 0ull;
-    {
-        const int q = wave * 32 + (lane & 31);
-        if (q >= P.nq) {
-            tau_key = ~0ull;
-            tau_f = __builtin_inff();
-        } else if (P.tau_init) {
-            tau_key = P.tau_init[q];
-            if (tau_key) tau_f = cmr_key_score(tau_key);
+    float rmin[NT], rmax[NT], tau_f[NT];
+    u64 tau_key[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        rmin[t] = __builtin_inff(); rmax[t] = -__builtin_inff(); tau_f[t] = -__builtin_inff();
+        tau_key[t] = 0ull;
+        const int q = (wave * NT + t) * 32 + (lane & 31);
+        if (q >= P.nq) {                         // padding query (all-zero operand): nothing may pass
+            tau_key[t] = ~0ull;
+            tau_f[t] = __builtin_inff();
+        } else if (P.tau_init) {                 // a valid lower bound on the global k-th best key
+            tau_key[t] = P.tau_init[q];
+            if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
         }
     }
-    u64* list_w = P.lists + ((size_t)blockIdx.x * NQB + (size_t)wave * 32) * CAP;
+    u64* list_w = P.lists + ((size_t)blockIdx.x * NQB + (size_t)wave * NT * 32) * CAP;
     __syncthreads();
 
-    if (p1 > p0) {
-        static_assert(!STAG || (WAVES == 8 && GRP == 8 && (KS / GRP) % 2 == 0 && NSTG % 2 == 0 && ABL == 0), "stagger geometry");
-        const int half = wave >> 2;                          // 0: loads even groups, 1: odd groups (STAG only)
-        const int wslot = STAG ? (wave & 3) : wave;          // first block of the group this wave moves
-        const char* gsrc = reinterpret_cast<const char*>(P.corpus + (size_t)p0 * KS * 64) + (size_t)wslot * 1024 + (size_t)lane * 16;
-        const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wslot * 1024u;
-        auto dma_group = [&](const char* g_src, int stage) {
-            const unsigned dst = lds_base + (unsigned)stage * (GRP * 1024u);   // wave-uniform LDS byte address
+    if (s1 > s0) {
+        const unsigned long long pbytes = (unsigned long long)pstride * KS * 1024ull;          // bytes between scanned panels
+        const char* cbase = reinterpret_cast<const char*>(P.corpus);
+        const char* last_group = cbase + (unsigned long long)(s1 - 1) * pbytes + (GPP - 1) * GRP * 1024;
+        const unsigned voff = (unsigned)lane * 16u + (unsigned)wave * 1024u;                    // piece j of wave w = block j*WAVES + w of its group
+        const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u;
+        // one DMA piece: 1 KiB from (wave-uniform base + voff) to LDS byte address dst
+        auto dma_piece = [&](const char* base, unsigned dst) {
             unsigned keep;
-            if constexpr (STAG) {                            // blocks wslot and wslot + 4 of the group
-                const char* g_src2 = g_src + 4096;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                             "s_add_u32 m0, %3, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g_src), "v"(g_src2), "s"(dst) : "memory", "scc");
-            } else if constexpr (PPG == 1) {
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g_src), "s"(dst) : "memory");
-            } else {
-                const char* g_src2 = g_src + WAVES * 1024;          // piece j of wave w is block w + j*WAVES of the group
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                             "s_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(g_src), "v"(g_src2), "s"(dst), "n"(WAVES * 1024) : "memory", "scc");
-            }
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
         };
+        // prologue: groups 0 .. NST-2 of this workgroup's stream (clamped to its last group)
 #pragma unroll
-        for (int d = 0; d < NST - 1; ++d)
-            if (!STAG || half == (d & 1)) dma_group(gsrc + (size_t)d * GRP * 1024, d);
-        gsrc += (size_t)(NST - 1) * GRP * 1024;
-        int st = 0;                                   // stage holding the current group
-        // group 0 must be complete before the first reads; from then on the barrier of iteration g
-        // validates group g+1, so the reads of group g are issued BEFORE that barrier and the MFMA
-        // chain never drains at a barrier (measured: ~600 of 1100 cycles per group were that bubble)
-        if constexpr (STAG) {
-            // half 0 issued groups 0, 2, .. NST-2 (two pieces each): group 0 has landed once <= NST-2 pieces are out.
-            // In iteration g the loaders of group g+1 (== those of group g+NST-1) have issued, after it, the groups
-            // g+3, g+5, .. g+NST-3: NST-4 pieces may stay in flight.
-            if (half == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST - 2) : "memory");
-            asm volatile("s_barrier" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 2)) : "memory");
+        for (int d = 0; d < NST - 1; ++d) {
+            const int dp = s0 + d / GPP;
+            const char* src = dp < s1 ? cbase + (unsigned long long)dp * pbytes + (d % GPP) * GRP * 1024 : last_group;
+#pragma unroll
+            for (int j = 0; j < PPG; ++j) dma_piece(src + j * WIDE_WAVES * 1024, lds_base + (unsigned)(d * GRP + j * WIDE_WAVES) * 1024u);
         }
-
-        for (int p = p0; p < p1; ++p) {
-            f32x16 acc;
+        // group 0 must be complete before the first reads; from then on the barrier of group g validates
+        // group g+1, so the LDS read-ahead never has to stop at a group or panel boundary
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 2)) : "memory");
+        int st = 0;                                   // stage holding the current group
+        const v4u* buf = stage_lds + lane;            // current stage, this lane's slot
+        v4u a[ADEPTH];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int u = 0; u < ADEPTH; ++u) a[u] = buf[u * 64];
+
+        const char* pbase = cbase + (unsigned long long)s0 * pbytes;     // panel s (wave-uniform)
+        for (int s = s0; s < s1; ++s) {
+            f32x16 acc[NT];
 #pragma unroll
             for (int g = 0; g < GPP; ++g) {
-                const v4u* buf = stage_lds + (size_t)st * GRP * 64 + lane;
-                constexpr int ADEPTH = BURST == 2 ? 4 : (WAVES == 8 ? 3 : 4);   // blocks read ahead of the barrier
-                v4u a[BURST == 2 ? 6 : ADEPTH];
-#pragma unroll
-                for (int u = 0; u < ADEPTH; ++u) a[u] = buf[u * 64];
-                if constexpr (STAG) {
-                    const bool loader = half == ((g + 1) & 1);
-                    if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST - 4) : "memory");
-                    asm volatile("s_barrier" ::: "memory");
-                    if (loader) dma_group(gsrc + (size_t)g * GRP * 1024, st == 0 ? NST - 1 : st - 1);
-                } else
-                if constexpr (ABL == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPG * (NST - 3)) : "memory");
-                else if constexpr (ABL == 2 || ABL == 5) asm volatile("s_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
-                if constexpr (!STAG && ABL != 2 && ABL != 5) dma_group(gsrc + (size_t)g * GRP * 1024, st == 0 ? NST - 1 : st - 1);
-                if constexpr (BURST == 2) {
-#pragma unroll
-                    for (int pr = 0; pr < GRP / 2; ++pr) {
-                        const int ks0 = g * GRP + 2 * pr, ks1 = ks0 + 1;
-                        v4u b0 = ks0 < KREG ? qreg[ks0 < KREG ? ks0 : 0] : qlds[(ks0 < KREG ? 0 : ks0 - KREG) * 64];
-                        v4u b1 = ks1 < KREG ? qreg[ks1 < KREG ? ks1 : 0] : qlds[(ks1 < KREG ? 0 : ks1 - KREG) * 64];
-                        v4u a0 = a[(2 * pr) % 6], a1 = a[(2 * pr + 1) % 6];
-                        __builtin_amdgcn_sched_barrier(0);
-                        // ONE lgkmcnt wait, in front of the pair: both MFMAs consume the statement's outputs, so it
-                        // cannot sink between them (an input-only statement did, and split the wait again)
-                        if (ks1 < KREG) asm volatile("" : "+v"(a0), "+v"(a1));
-                        else if (ks0 < KREG) asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b1));
-                        else asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
-                        acc = CmrBlk<DT>::mma(a0, b0, acc);
-                        acc = CmrBlk<DT>::mma(a1, b1, acc);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (2 * pr + 4 < GRP) {                                  // operands of the pair after next
-                            a[(2 * pr + 4) % 6] = buf[(2 * pr + 4) * 64];
-                            a[(2 * pr + 5) % 6] = buf[(2 * pr + 5) * 64];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
+                // prefetch cursor: group g + NST-1 of the stream, into the stage everybody just left
+                constexpr int dgi_dummy = 0; (void)dgi_dummy;
+                const int dps = s + (g + NST - 1) / GPP;
+                const char* dsrc = dps < s1 ? pbase + (unsigned long long)((g + NST - 1) / GPP) * pbytes + ((g + NST - 1) % GPP) * GRP * 1024 : last_group;
+                const unsigned ddst = lds_base + (unsigned)(st == 0 ? NST - 1 : st - 1) * (GRP * 1024u);
+                const int stn = st + 1 == NST ? 0 : st + 1;
+                const v4u* bufn = stage_lds + (size_t)stn * GRP * 64 + lane;
 #pragma unroll
                 for (int u = 0; u < GRP; ++u) {
+                    if (u % DSTEP == 0) dma_piece(dsrc + (u / DSTEP) * WIDE_WAVES * 1024, ddst + (unsigned)(u / DSTEP) * WIDE_WAVES * 1024u);
                     const v4u a_use = a[u % ADEPTH];
                     __builtin_amdgcn_sched_barrier(0);
                     const int ks = g * GRP + u;
-                    const v4u b = ks < KREG ? qreg[ks < KREG ? ks : 0] : qlds[(ks < KREG ? 0 : ks - KREG) * 64];
-                    if constexpr (ABL == 1 || ABL == 4) asm volatile("" ::"v"(a_use), "v"(b));
-                    else acc = CmrBlk<DT>::mma(a_use, b, acc);
-                    if (u + ADEPTH < GRP) a[u % ADEPTH] = buf[(u + ADEPTH) * 64];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        // register file of the resident B-operand: tile 0 in VGPRs, tile 1 in AGPRs (NT = 2);
+                        // first / second half of the k-steps (NT = 1).  The accumulators are AGPRs.
+                        const int ab = NT == 2 ? t : (ks >= KS / 2 ? 1 : 0);
+                        if (ks < KREG) {
+                            CmrBlk<DT>::mma_asm(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
+                        } else {
+                            const v4u b = qlds[(t * KLDS + (ks < KREG ? 0 : ks - KREG)) * 64];
+                            CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
+                        }
+                    }
+                    a[u % ADEPTH] = u + ADEPTH < GRP ? buf[(u + ADEPTH) * 64] : bufn[(u + ADEPTH - GRP) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                st = st + 1 == NST ? 0 : st + 1;
+                st = stn;
+                buf = bufn;
             }
-            gsrc += (size_t)KS * 1024;
+            pbase += pbytes;
+            cmr_mfma_drain<NT>(acc);          // MFMA results -> VALU readers: wait states hipcc does not insert for asm
 
-            if constexpr (ABL >= 4) {   // ablation: keep acc alive, skip the epilogue
-                asm volatile("" ::"v"(acc));
-                continue;
+            const unsigned row0 = (unsigned)s * (unsigned)pstride * CMR_PANEL_ROWS;     // < 2^32 rows per shard (cmr_index_append)
+            int nvalid = CMR_PANEL_ROWS;
+            const bool partial = (long long)row0 + CMR_PANEL_ROWS > P.nrows;            // only the corpus' last panel
+            if (__builtin_expect(partial, 0)) {
+                nvalid = (int)(P.nrows - (long long)row0);
+                asm volatile("" : "+s"(nvalid));      // keeps the masked variant's arithmetic inside this branch
             }
-            const long long row0 = (long long)p * CMR_PANEL_ROWS;
-            const bool partial = row0 + CMR_PANEL_ROWS > P.nrows;
-            float mx, mn;
-            if (!partial) {
-                mx = acc[0]; mn = acc[0];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) { mx = fmaxf(mx, acc[r]); mn = fminf(mn, acc[r]); }
-            } else {
-                mx = -__builtin_inff(); mn = __builtin_inff();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = row0 + cmr_acc_row(r, lane) < P.nrows;
-                    mx = fmaxf(mx, ok ? acc[r] : -__builtin_inff());
-                    mn = fminf(mn, ok ? acc[r] : __builtin_inff());
-                }
-            }
-            rmax = fmaxf(rmax, mx);
-            rmin = fminf(rmin, mn);
-            if (__any(mx >= tau_f)) {
-                const u64 need = topk_push<CAP>(acc, row0, P.nrows, tau_key, cnt_w, list_w, lane);
-                if (need) {
-                    // address-taken copies live only inside this branch (passing &tau_f itself would pin
-                    // it to scratch and its reload's s_waitcnt vmcnt(0) would drain the DMA ring on
-                    // every panel)
-                    u64 tk = tau_key;
-                    float tf = tau_f;
-                    topk_compact_call<CAP>(need, P.k, &tk, &tf, cnt_w, list_w, cstage, lane);
-                    tau_key = tk;
-                    tau_f = tf;
-                    // retire the scratch reloads of tk / tf HERE: otherwise hipcc waits for them at their
-                    // next use — an unconditional s_waitcnt vmcnt(0) in front of every panel's threshold
-                    // compare, which drains the DMA ring each time
-                    asm volatile("" : "+v"(tau_key), "+v"(tau_f));
+            for (int t = 0; t < NT; ++t) {
+                const float mx = __builtin_expect(partial, 0) ? wide_minmax_partial(acc[t], nvalid, lane, rmin[t], rmax[t])
+                                                              : wide_minmax(acc[t], rmin[t], rmax[t]);
+                if (__any(mx >= tau_f[t])) {
+                    const u64 need = wide_push<CAP>(acc[t], row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane);
+                    if (need) wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
                 }
             }
         }
     }
 
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    {
-        const float mn = fminf(rmin, __shfl_xor(rmin, 32));
-        const float mx = fmaxf(rmax, __shfl_xor(rmax, 32));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float mn = fminf(rmin[t], __shfl_xor(rmin[t], 32));
+        const float mx = fmaxf(rmax[t], __shfl_xor(rmax[t], 32));
         if (lane < 32) {
-            const int q = wave * 32 + lane;
+            const int q = (wave * NT + t) * 32 + lane;
             P.mm[(size_t)blockIdx.x * NQB + q] = make_float2(mn, mx);
-            P.cnt[(size_t)blockIdx.x * NQB + q] = __hip_atomic_load(&cnt_w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            P.cnt[(size_t)blockIdx.x * NQB + q] = __hip_atomic_load(&cnt_w[t * 32 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
 
-static int wide_waves(int ks) { return ks == 48 ? 8 : 4; }
+// geometry of the wide kernel per shape: query tiles per wave, LDS ring depth, k-steps of a tile served from LDS
+static int wide_nt(int ks) { return ks == 48 ? 2 : 1; }
+#define WIDE_NST_48 8
+#define WIDE_KLDS_48 0
+#define WIDE_NST_64 8
+#define WIDE_KLDS_64 0
 
-size_t cmr_wide_lds_bytes(int ks, int cap, int variant) {
-    const int waves = wide_waves(ks);
-    const int klds = waves == 8 ? 4 : 0;
-    (void)variant;                        // every variant built so far has the same footprint
-    // the corpus ring is 96 KiB for every (group, stages) variant
-    return (size_t)WIDE_STAGES * WIDE_GROUP * 1024 + (size_t)waves * 32 * 4 + (size_t)waves * (cap + 2) * 8 +
-           (size_t)waves * klds * 1024;
+size_t cmr_wide_lds_bytes(int ks, int cap) {
+    const int nt = wide_nt(ks);
+    const int nst = ks == 48 ? WIDE_NST_48 : WIDE_NST_64;
+    const int klds = ks == 48 ? WIDE_KLDS_48 : WIDE_KLDS_64;
+    return (size_t)nst * WIDE_GROUP * 1024 + (size_t)WIDE_WAVES * nt * 32 * 4 + (size_t)WIDE_WAVES * (cap + 2) * 8 +
+           (size_t)WIDE_WAVES * nt * klds * 1024;
 }
 
-// wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 8 waves x 32 = 256 queries per pass),
-// ks = 64 (1024-d: a tile needs 256 registers -> 4 waves x 32 = 128 queries per pass)
+// wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 4 waves x 2 tiles x 32 = 256 queries per pass),
+// ks = 64 (1024-d: a tile needs 256 registers -> 4 waves x 1 tile x 32 = 128 queries per pass)
 int cmr_wide_queries(int dtype, int dpad) {
     if (dtype == CMR_DT_F32) return 0;
     if (dpad == 768) return 256;
@@ -663,45 +710,20 @@ int cmr_wide_queries(int dtype, int dpad) {
     return 0;
 }
 
-hipError_t cmr_launch_scan_wide(const CmrScanGeom& gin, const CmrScanArgs& a, hipStream_t s) {
-    CmrScanGeom g = gin;
-    if (g.wide_group < 0 && g.ks != 48) g.wide_group = 0;      // experimental variants exist for the 8-wave (768-d) shape only
+hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
     const ScanP p = to_p(g, a);
-    const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap, g.wide_group);
-    auto launch = [&](auto kern, int threads) -> hipError_t {
+    const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap);
+    auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(threads), lds, s, p);
+        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(WIDE_WAVES * 64), lds, s, p);
         return hipGetLastError();
     };
-    const int abl = getenv("CMR_WIDE_ABL") ? atoi(getenv("CMR_WIDE_ABL")) : 0;
-    if (abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128) {
-        if (abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 1>, 512);
-        if (abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 2>, 512);
-        if (abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 3>, 512);
-        if (abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 4>, 512);
-        if (abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 5>, 512);
-        if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 8, 128, 6>, 512);
-    }
-    static_assert(WIDE_STAGES * WIDE_GROUP == 6 * 16, "ring variants share one LDS size");
-    if (g.wide_group == -2 && g.ks == 48) {     // experimental: paired MFMA issue (CMR_WIDE_BURST=1), 16-block groups
-#define WCASEB(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 16, 6, 0, 2>, 512);
-        WCASEB(CMR_DT_BF16, 128) WCASEB(CMR_DT_BF16, 256) WCASEB(CMR_DT_F16, 128) WCASEB(CMR_DT_F16, 256)
-#undef WCASEB
-    }
-    if (g.wide_group == -1 && g.ks == 48) {     // experimental: staggered DMA issue (CMR_WIDE_STAGGER=1)
-#define WCASES(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 8, 12, 1>, 512);
-        WCASES(CMR_DT_BF16, 128) WCASES(CMR_DT_BF16, 256) WCASES(CMR_DT_F16, 128) WCASES(CMR_DT_F16, 256)
-#undef WCASES
-    }
-    if (g.wide_group == 16 && g.ks == 48) {     // experimental: 16-block groups, 6 stages (8-wave variants only)
-#define WCASE16(DT, CAPV) if (g.dtype == DT && g.cap == CAPV) return launch(scan_wide_kernel<DT, 48, 8, CAPV, 0, 16, 6>, 512);
-        WCASE16(CMR_DT_BF16, 128) WCASE16(CMR_DT_BF16, 256) WCASE16(CMR_DT_F16, 128) WCASE16(CMR_DT_F16, 256)
-#undef WCASE16
-    }
-#define WCASE(DT, KSV, WV, CAPV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV) return launch(scan_wide_kernel<DT, KSV, WV, CAPV>, WV * 64);
-    WCASE(CMR_DT_BF16, 48, 8, 128) WCASE(CMR_DT_BF16, 48, 8, 256) WCASE(CMR_DT_F16, 48, 8, 128) WCASE(CMR_DT_F16, 48, 8, 256)
-    WCASE(CMR_DT_BF16, 64, 4, 128) WCASE(CMR_DT_BF16, 64, 4, 256) WCASE(CMR_DT_F16, 64, 4, 128) WCASE(CMR_DT_F16, 64, 4, 256)
+#define WCASE(DT, KSV, NTV, CAPV, NSTV, KLV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV) return launch(scan_wide_kernel<DT, KSV, NTV, CAPV, NSTV, KLV>);
+    WCASE(CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48) WCASE(CMR_DT_BF16, 48, 2, 256, WIDE_NST_48, WIDE_KLDS_48)
+    WCASE(CMR_DT_F16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48) WCASE(CMR_DT_F16, 48, 2, 256, WIDE_NST_48, WIDE_KLDS_48)
+    WCASE(CMR_DT_BF16, 64, 1, 128, WIDE_NST_64, WIDE_KLDS_64) WCASE(CMR_DT_BF16, 64, 1, 256, WIDE_NST_64, WIDE_KLDS_64)
+    WCASE(CMR_DT_F16, 64, 1, 128, WIDE_NST_64, WIDE_KLDS_64) WCASE(CMR_DT_F16, 64, 1, 256, WIDE_NST_64, WIDE_KLDS_64)
 #undef WCASE
     return hipErrorInvalidValue;
 }

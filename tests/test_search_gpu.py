@@ -84,6 +84,29 @@ def test_wide_batch_register_resident_queries(dtype, d, nq):
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
 
 
+@pytest.mark.parametrize("env", [{}, {"CMR_SCAN_NO_SAMPLE": "1"}])
+@pytest.mark.parametrize("n", [60_000, 9_000])
+def test_wide_batch_ascending_scores_force_compaction(n, env):
+    """Adversarial order for the running top-k: every query's score grows with the row index, so each panel beats
+    the threshold and the per-workgroup candidate lists overflow and compact (wide kernel's wide_compact); with
+    and without the sampling thresholds; also at sizes where a workgroup scans a single panel."""
+    rng = np.random.default_rng(n)
+    u = rng.standard_normal(768).astype(np.float32); u /= np.linalg.norm(u)
+    X = 0.25 * rng.standard_normal((n, 768)).astype(np.float32) / np.sqrt(768) + np.linspace(0.0, 1.0, n, dtype=np.float32)[:, None] * u
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    Q = u[None, :] + 0.05 * rng.standard_normal((200, 768)).astype(np.float32) / np.sqrt(768)
+    Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    a_ids, a_sc = _check("bf16", X, Q, 20, env=env)
+    b_ids, b_sc = _check("bf16", X, Q, 20, env={**env, "CMR_SCAN_NO_WIDE": "1"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+
+
+@pytest.mark.parametrize("n", [1, 31, 100, 1025])
+def test_wide_batch_tiny_corpora(n):
+    X, Q = _mk(n, 768, 256, seed=n)
+    _check("bf16", X, Q, 20)
+
+
 def test_wide_batch_large_k_and_sampling():
     X, Q = _mk(300_000, 768, 256, seed=5)          # large enough for both sampling levels
     _check("bf16", X, Q, 100)
