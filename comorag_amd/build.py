@@ -108,7 +108,7 @@ def audit_ring(asm_text: str) -> dict:
     return result
 
 
-_WIDE_RE = re.compile(r"^_Z16scan_wide_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
+_WIDE_RE = re.compile(r"^_Z16scan_wide_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi0EEv5ScanP:")   # ABL = 0 only
 
 
 def audit_wide(asm_text: str) -> dict:

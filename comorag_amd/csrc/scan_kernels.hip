@@ -521,7 +521,9 @@ __device__ __forceinline__ void wide_compact(u64 need, int k, u64& tau_key, floa
     }
 }
 
-template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS>
+// ABL: developer ablations (CMR_WIDE_ABL, results are wrong by design): 1 no MFMA, 2 no DMA in the loop, 3 no epilogue,
+// 4 min/max but no threshold test / slow path, 5 no barrier in the loop, 6 = 2 + no LDS reads, 7 = 2 + no barrier
+template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS, int ABL = 0>
 __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) {
     constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = WIDE_ADEPTH;
     static_assert(KS % GRP == 0 && GRP % WIDE_WAVES == 0 && GRP % ADEPTH == 0 && NST >= 4, "group geometry");
@@ -619,7 +621,10 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
             f32x16 acc[NT];
 #pragma unroll
             for (int g = 0; g < GPP; ++g) {
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
+                if constexpr (ABL == 2 || ABL == 6) asm volatile("s_barrier" ::: "memory");
+                else if constexpr (ABL == 7) {}
+                else if constexpr (ABL == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPG * (NST - 3)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
                 // prefetch cursor: group g + NST-1 of the stream, into the stage everybody just left
                 constexpr int dgi_dummy = 0; (void)dgi_dummy;
                 const int dps = s + (g + NST - 1) / GPP;
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                 const v4u* bufn = stage_lds + (size_t)stn * GRP * 64 + lane;
 #pragma unroll
                 for (int u = 0; u < GRP; ++u) {
-                    if (u % DSTEP == 0) dma_piece(dsrc + (u / DSTEP) * WIDE_WAVES * 1024, ddst + (unsigned)(u / DSTEP) * WIDE_WAVES * 1024u);
+                    if (ABL != 2 && ABL != 6 && ABL != 7 && u % DSTEP == 0) dma_piece(dsrc + (u / DSTEP) * WIDE_WAVES * 1024, ddst + (unsigned)(u / DSTEP) * WIDE_WAVES * 1024u);
                     const v4u a_use = a[u % ADEPTH];
                     __builtin_amdgcn_sched_barrier(0);
                     const int ks = g * GRP + u;
@@ -638,6 +643,11 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                         // register file of the resident B-operand: tile 0 in VGPRs, tile 1 in AGPRs (NT = 2);
                         // first / second half of the k-steps (NT = 1).  The accumulators are AGPRs.
                         const int ab = NT == 2 ? t : (ks >= KS / 2 ? 1 : 0);
+                        if constexpr (ABL == 1) {
+                            if (ab) asm volatile("" ::"v"(a_use), "a"(qreg[t][ks < KREG ? ks : 0]));
+                            else asm volatile("" ::"v"(a_use), "v"(qreg[t][ks < KREG ? ks : 0]));
+                            if (ks == 0) asm volatile("" : "=a"(acc[t]));
+                        } else
                         if (ks < KREG) {
                             CmrBlk<DT>::mma_asm(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
                         } else {
@@ -645,7 +655,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                             CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
                         }
                     }
-                    a[u % ADEPTH] = u + ADEPTH < GRP ? buf[(u + ADEPTH) * 64] : bufn[(u + ADEPTH - GRP) * 64];
+                    if constexpr (ABL != 6) a[u % ADEPTH] = u + ADEPTH < GRP ? buf[(u + ADEPTH) * 64] : bufn[(u + ADEPTH - GRP) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 st = stn;
@@ -653,6 +663,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
             }
             pbase += pbytes;
             cmr_mfma_drain<NT>(acc);          // MFMA results -> VALU readers: wait states hipcc does not insert for asm
+            if constexpr (ABL == 3) continue;
 
             const unsigned row0 = (unsigned)s * (unsigned)pstride * CMR_PANEL_ROWS;     // < 2^32 rows per shard (cmr_index_append)
             int nvalid = CMR_PANEL_ROWS;
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
             for (int t = 0; t < NT; ++t) {
                 const float mx = __builtin_expect(partial, 0) ? wide_minmax_partial(acc[t], nvalid, lane, rmin[t], rmax[t])
                                                               : wide_minmax(acc[t], rmin[t], rmax[t]);
-                if (__any(mx >= tau_f[t])) {
+                if (ABL != 4 && __any(mx >= tau_f[t])) {
                     const u64 need = wide_push<CAP>(acc[t], row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane);
                     if (need) wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
                 }
@@ -719,6 +730,16 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipS
         hipLaunchKernelGGL(kern, dim3(g.grid), dim3(WIDE_WAVES * 64), lds, s, p);
         return hipGetLastError();
     };
+    const int abl = getenv("CMR_WIDE_ABL") ? atoi(getenv("CMR_WIDE_ABL")) : 0;
+    if (abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128) {
+        if (abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 1>);
+        if (abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 2>);
+        if (abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 3>);
+        if (abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 4>);
+        if (abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 5>);
+        if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 6>);
+        if (abl == 7) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 7>);
+    }
 #define WCASE(DT, KSV, NTV, CAPV, NSTV, KLV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV) return launch(scan_wide_kernel<DT, KSV, NTV, CAPV, NSTV, KLV>);
     WCASE(CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48) WCASE(CMR_DT_BF16, 48, 2, 256, WIDE_NST_48, WIDE_KLDS_48)
     WCASE(CMR_DT_F16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48) WCASE(CMR_DT_F16, 48, 2, 256, WIDE_NST_48, WIDE_KLDS_48)
