@@ -118,6 +118,7 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
+    int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
     int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
     int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves free (-1 = by corpus size, see enqueue_pass)
     std::mutex pipe_mu;
@@ -291,7 +292,11 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         const long long s0 = std::max<long long>(16, k);                       // panels
         level_panels[n_levels++] = s0;
         if (npanels >= 4096) {
-            long long s1 = std::min<long long>(std::max<long long>(npanels / idx->sample_div, 8 * s0), 128 * s0);
+            // wide kernel: 256 queries share a workgroup, so ANY of 8 tiles beating its threshold stalls all four waves at
+            // the next barrier — a 4x larger level-1 sample (N/32 rows up to 512 x level 0) took the main pass from 4.09 to
+            // 3.76 ms at 10 M rows; the sample itself is cheap there (256 queries per pass over it)
+            const long long maxmul = idx->sample_maxmul > 0 ? idx->sample_maxmul : (wide ? 512 : 128);
+            long long s1 = std::min<long long>(std::max<long long>(npanels / idx->sample_div, 8 * s0), maxmul * s0);
             if (!wide) s1 = std::min<long long>(s1, kMaxMergeLists);
             if (s1 < npanels / 2) level_panels[n_levels++] = s1;
         }
@@ -302,12 +307,12 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         if (!max_sample) reserve_cus = 0;
         else if (wide) {
             // Pipelined mode, wide kernel: a sampling workgroup owns a CU (512 registers per wave), so the next batch's
-            // pre-phase runs on reserved CUs: ~120 us of dependent small kernels + S1 panels at ~2.5 us each (MFMA-paced,
-            // slowed by the saturating main scan) have to fit under ~60 % of this scan.  The main scan is HBM-bound with
-            // the matrix pipe ~65 % busy, so a few CUs are cheap; 1/4 of the chip is the cap.
-            const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
-            const double room = std::max(0.6 * scan_us - 120.0, 25.0);
-            reserve_cus = (int)std::min<double>(idx->n_cu / 4, std::max(8.0, std::ceil((double)max_sample * 2.5 / room)));
+            // pre-phase runs on reserved CUs.  Workgroups are bound to a shader engine (8 CUs) at dispatch and then wait for
+            // a free CU THERE: with 240 + 16 workgroups in flight some engines were full and a 16-workgroup sampling pass
+            // waited 4.4 ms for the main scan to end (kernel trace), while 224 + 32 — one free CU in every one of the 32
+            // engines — flows.  So the reserve is one CU per shader engine; the main pass is matrix-pipe-bound and pays for
+            // them in proportion (4.2 -> 4.6 ms at 10 M rows), about what a serialised pre-phase would cost.
+            reserve_cus = 32;
         } else {
             // Pipelined mode, reserve chosen by size: the next batch's pre-phase has to fit under this scan (~6 TB/s).
             // It is ~200 us of dependent small kernels plus ~200 us per round of its largest sampling pass on the
@@ -324,8 +329,11 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     // workgroups of a sampling pass over spn panels, and candidate lists it produces
     auto sample_grid = [&](long long spn) -> int {
         if (!wide) return (int)((spn + lists_per_wg - 1) / lists_per_wg);
+        // at most 48 sampled panels per workgroup: a level-1 pass pushes ~1 key per query and panel, and a candidate list
+        // that fills up (CAP - 32 keys) costs a compaction, whose global loads drain the workgroup's DMA ring.  More
+        // workgroups than (reserved) CUs simply run in rounds.
         const int cap_wgs = pipelined && reserve_cus > 0 ? reserve_cus : idx->n_cu;
-        return (int)std::min<long long>(spn, cap_wgs);
+        return (int)std::min<long long>(spn, std::max<long long>(cap_wgs, (spn + 47) / 48));
     };
     const int Ws = max_sample ? std::max(sample_grid(level_panels[0]), n_levels > 1 ? sample_grid(level_panels[1]) : 0) * lists_per_wg : 0;
     int NQ, W, tiles;
@@ -365,7 +373,12 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         const int Wl = gs.grid * lists_per_wg;
         CmrScanArgs as = a;
         as.lists = (u64*)ws->s_lists.p; as.cnt = (int*)ws->s_cnt.p; as.mm = (float2*)ws->s_mm.p;
-        as.sample_waves = (int)spn; as.sample_stride = (int)(npanels / spn);
+        // chunks of 8 consecutive panels (384 KiB at 768-d bf16), chunk starts spread evenly over the corpus: a sampling
+        // workgroup that hops one panel at a time pays a TLB miss / DRAM page run per 48 KiB (measured 11-14 us per
+        // panel under a saturating main scan)
+        const int clog = spn >= 64 ? 3 : 0;
+        const long long nchunks = (spn + (1 << clog) - 1) >> clog;
+        as.sample_waves = (int)spn; as.sample_chunk_log2 = clog; as.sample_stride = (int)(npanels / nchunks);
         u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
         HIP_TRY(wide ? cmr_launch_scan_wide(gs, as, sp) : cmr_launch_scan_topk(gs, as, sp));
         HIP_TRY(cmr_launch_merge_query((const u64*)ws->s_lists.p, (const int*)ws->s_cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
@@ -607,6 +620,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
     idx->sample_div = std::max(2, env_int("CMR_SAMPLE_DIV", 32));
+    idx->sample_maxmul = std::max(0, env_int("CMR_SAMPLE_MAXMUL", 0));
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);

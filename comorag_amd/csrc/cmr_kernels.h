@@ -37,9 +37,12 @@ struct CmrScanArgs {
     float* scores;        // [nq][ld]
     long long ld;
     int nq;
-    // sampling pass (top-k mode): wave w < sample_waves scans panel w*sample_stride only
+    // sampling pass (top-k mode): sample_waves panels in chunks of 2^sample_chunk_log2 consecutive panels, chunk starts
+    // sample_stride panels apart: sampled panel s is panel (s >> c) * sample_stride + (s & (2^c - 1)).  Narrow kernel:
+    // wave w < sample_waves scans sampled panel w only; wide kernel: the grid's workgroups split the sampled panels.
     int sample_waves;
     int sample_stride;
+    int sample_chunk_log2;
     const u64* tau_init;  // [nqt*32] initial threshold keys or nullptr
 };
 

@@ -43,8 +43,9 @@ struct ScanP {
     float* scores;
     long long ld;
     int nq;
-    int sample_waves;      // > 0: sampling pass — wave w (< sample_waves) scans the single panel w*sample_stride
-    int sample_stride;
+    int sample_waves;      // > 0: sampling pass over sample_waves panels; sampled panel s = (s >> c) * sample_stride + (s & (2^c - 1))
+    int sample_stride;     //      (chunks of 2^c consecutive panels: one TLB reach / DRAM page run per chunk instead of per panel)
+    int sample_chunk_log2;
     const u64* tau_init;   // per-query initial threshold keys (from the sampling pass) or nullptr
 };
 
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     const int gw = blockIdx.x * CMR_SCAN_WAVES + wave;
     int p0, p1;
     if (P.sample_waves > 0) {   // sampling pass: one strided panel per wave
-        p0 = gw * P.sample_stride;
+        p0 = (gw >> P.sample_chunk_log2) * P.sample_stride + (gw & ((1 << P.sample_chunk_log2) - 1));
         p1 = gw < P.sample_waves ? p0 + 1 : p0;
     } else {
         p0 = (int)(((long long)gw * P.npanels) / W);
@@ -372,7 +373,7 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.nrows = a.nrows; p.npanels = a.npanels; p.ks = g.ks; p.k = a.k;
     p.lists = a.lists; p.cnt = a.cnt; p.mm = a.mm;
     p.scores = a.scores; p.ld = a.ld; p.nq = a.nq;
-    p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.tau_init = a.tau_init;
+    p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.sample_chunk_log2 = a.sample_chunk_log2; p.tau_init = a.tau_init;
     return p;
 }
 
@@ -400,16 +401,16 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 //   * Budget per CU and 32-row panel at 768-d: 4 SIMDs x 96 MFMAs x 32 cycles = 3072 cycles, 192 KiB
 //     of ds_read_b128 = 768 cycles, 48 KiB of HBM = ~4900 cycles at the achievable rate: HBM-bound with
 //     the matrix pipe ~63 % busy.
-//   * A workgroup scans the panels {s * pstride : s in [s0, s1)} — pstride = 1 for the main pass, the
-//     sample stride for a sampling pass (a sampling workgroup takes MANY strided panels: loading the
-//     384 KiB of query fragments is the fixed cost of a workgroup).  The prefetch cursor is clamped to
-//     the workgroup's last group, so nothing is read outside [first, last] panel of the range.
+//   * A workgroup scans the (sampled) panels s in [s0, s1): all panels for the main pass; for a sampling pass chunks of
+//     consecutive panels spread over the corpus, MANY per workgroup (loading the 384 KiB of query fragments is the fixed
+//     cost of a workgroup).  The prefetch cursor is clamped to the workgroup's last group, so nothing outside its
+//     panels is ever read.
 // The top-k epilogue, candidate lists and thresholds are the per-wave ones of scan_kernel; list /
 // counter rows are laid out [workgroup][4*NT*32 queries] so merge_query_kernel consumes them with
 // W = gridDim.x.
 #define WIDE_WAVES 4
 #define WIDE_GROUP 16     // blocks per staged group
-#define WIDE_ADEPTH 4     // blocks read ahead from LDS per wave
+#define WIDE_ADEPTH 8     // LDS read-ahead ring of a wave, in blocks (two quads: one in use, one landing)
 
 // Epilogue pieces of the wide kernel.  The wave's register file is full of query fragments, and hipcc's allocator
 // spills the values with the longest live range first — the fragments — whenever ANY block of the loop needs more
@@ -457,34 +458,122 @@ __device__ __forceinline__ float wide_minmax_partial(const f32x16& acc, int nval
     rmax = wide_max3(rmax, mx, mx);
     return mx;
 }
-// topk_push with 32-bit rows, one value at a time.  Everything derived from the lane id is made opaque here: hipcc
-// would otherwise hoist sixteen per-register row offsets and the list pointers out of the panel loop, as
-// loop-invariant values that then live across the whole scan.
+// Candidate push of the wide kernel.
+//  * The filter is the float compare v >= tau_f alone — a superset of key > tau_key (it also admits rows that tie with
+//    the threshold score): any real (score, row) pair may sit in a candidate list, only the keys above the threshold must.
+//  * vmcnt counts every vector-memory instruction of the wave IN ORDER, so each global store issued here makes the
+//    scan's hand-counted "s_waitcnt vmcnt(N)" wait for one more DMA piece than it needs; a sampling pass (threshold from
+//    a 640-row sample: ~1 pass per query and panel, 28 store instructions per wave and panel) drained the whole ring on
+//    every panel that way (10-37 us per panel).  So: count first, ONE LDS atomic per lane reserves the lane's list slots
+//    and its slots in a per-wave LDS staging area, the keys go to the staging area as (key, destination) records, and the
+//    wave then stores the records cooperatively — ceil(T / 64) store instructions for T pushes, usually one.  The number
+//    of store instructions is returned in n_stores; the scan adds it to its wait counts (wide_wait_group).
+//  * 32-bit rows.  Everything derived from the lane id is made opaque here: hipcc would otherwise hoist sixteen
+//    per-register row offsets and the list pointers out of the panel loop, as loop-invariant values that then live
+//    across the whole scan (and evict query fragments).
+#define WIDE_STG 256      // staging records (16 B) per wave
+#define WIDE_AMOVE 8      // NT = 2: k-steps of tile 0 whose B-operand lives in the AGPR half
 template <int CAP>
-__device__ __forceinline__ u64 wide_push(const f32x16& acc, unsigned row0, int nvalid, u64 tau_key, float tau_f, int* cnt_t, u64* list_t,
-                                         int lane) {
+__device__ __forceinline__ u64 wide_push(const f32x16& acc, unsigned row0, int nvalid, float tau_f, int* cnt_t, u64* list_t, uint4* stg,
+                                         int* stg_tail, int lane, int& n_stores) {
+    int ql = lane & 31;
+    int hrow = 4 * (lane >> 5);
+    asm volatile("" : "+v"(ql), "+v"(hrow), "+v"(lane));
+    const unsigned rbase = row0 + (unsigned)hrow;
+    const int lim = nvalid - hrow;
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        n += ((r & 3) + 8 * (r >> 2) < lim && acc[r] >= tau_f) ? 1 : 0;
+        if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (lane == 0) *stg_tail = 0;                       // LDS operations of one wave execute in order
+    int slot = 0, pos = 0;
+    if (n) {
+        slot = atomicAdd(&cnt_t[ql], n);                // ds_add_rtn_u32; <= 32 pushes per query per panel (two lanes x 16)
+        pos = atomicAdd(stg_tail, n);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int T = __builtin_amdgcn_readfirstlane(*stg_tail);
+    if (T <= WIDE_STG) {
+        unsigned dsti = (unsigned)ql * CAP + (unsigned)slot;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            const int cr = (r & 3) + 8 * (r >> 2);
+            if (cr < lim && v >= tau_f) {
+                const u64 key = cmr_make_key(v, rbase + (unsigned)cr);
+                stg[pos++] = make_uint4((unsigned)key, (unsigned)(key >> 32), dsti++, 0u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma nounroll
+        for (int i = lane; i < T; i += 64) {
+            const uint4 rec = stg[i];
+            list_t[rec.z] = ((u64)rec.y << 32) | (u64)rec.x;
+        }
+        n_stores += (T + 63) >> 6;
+    } else {                                            // more pushes than the staging area holds: direct stores
+        u64* dst = list_t + (size_t)ql * CAP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            const int cr = (r & 3) + 8 * (r >> 2);
+            if (cr < lim && v >= tau_f) dst[slot++] = cmr_make_key(v, rbase + (unsigned)cr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        n_stores += 16;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // as topk_push: counters current, pushed keys fenced by the compaction
+    const int c = __hip_atomic_load(&cnt_t[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __ballot(c > CAP - 32) & 0xFFFFFFFFull;
+}
+// The same push for the MAIN pass, where a tile that beats the threshold does so with one or two values: one value at
+// a time behind the float pre-filter (a whole wave usually skips the register), key compare for the ties, one
+// returning LDS atomic and one store per pushed value; n_stores counts the store instructions.
+template <int CAP>
+__device__ __forceinline__ u64 wide_push_sparse(const f32x16& acc, unsigned row0, int nvalid, u64 tau_key, float tau_f, int* cnt_t, u64* list_t,
+                                                int lane, int& n_stores) {
     int ql = lane & 31;
     int hrow = 4 * (lane >> 5);
     asm volatile("" : "+v"(ql), "+v"(hrow));
     const unsigned rbase = row0 + (unsigned)hrow;
     const int lim = nvalid - hrow;
+    int top = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float v = acc[r];
-        // float pre-filter first (one compare; a whole wave usually skips the register): the key compare decides ties
         if (v >= tau_f) {
             const int cr = (r & 3) + 8 * (r >> 2);
             const u64 key = cmr_make_key(v, rbase + (unsigned)cr);
-            if (cr < lim && key > tau_key) {
+            const bool hit = cr < lim && key > tau_key;
+            n_stores += __any(hit) ? 1 : 0;
+            if (hit) {
                 const int slot = atomicAdd(&cnt_t[ql], 1);  // ds_add_rtn_u32; <= 32 pushes per query per panel
                 list_t[(size_t)ql * CAP + slot] = key;
+                top = slot + 1;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // as topk_push: counters current, pushed keys fenced by the compaction
-    const int c = __hip_atomic_load(&cnt_t[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return __ballot(c > CAP - 32) & 0xFFFFFFFFull;
+    // the atomics returned each pushing lane's slot: a list is nearly full when some push landed beyond CAP - 32
+    const u64 full = __ballot(top > CAP - 32);
+    return (full | (full >> 32)) & 0xFFFFFFFFull;
+}
+// "My DMA pieces of the next group have landed": at most `base` younger DMA pieces plus the x store instructions this
+// wave issued after them may still be in flight.  The wait count is an immediate, so x selects among a few (rounded
+// down: waiting for fewer outstanding operations than allowed is always safe).
+template <int BASE>
+__device__ __forceinline__ void wide_wait_group(int x) {
+    static_assert(BASE + 32 <= 63, "vmcnt is a 6-bit counter");
+    if (x == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+    else if (x == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 1) : "memory");
+    else if (x < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 2) : "memory");
+    else if (x < 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 4) : "memory");
+    else if (x < 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 8) : "memory");
+    else if (x < 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 16) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 32) : "memory");
 }
 // topk_compact for the wide kernel: the same rank-by-counting compaction, but every list element goes through the
 // LDS stage instead of being held in registers, and no loop is unrolled — about a dozen registers in all.  (An
@@ -526,7 +615,7 @@ __device__ __forceinline__ void wide_compact(u64 need, int k, u64& tau_key, floa
 template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS, int ABL = 0>
 __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) {
     constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = WIDE_ADEPTH;
-    static_assert(KS % GRP == 0 && GRP % WIDE_WAVES == 0 && GRP % ADEPTH == 0 && NST >= 4, "group geometry");
+    static_assert(KS % GRP == 0 && GRP % WIDE_WAVES == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && GRP / 4 == GRP / WIDE_WAVES && NST >= 4, "group geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -534,13 +623,18 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
     constexpr int NQB = WIDE_WAVES * NT * 32;     // queries per workgroup pass
     constexpr int GPP = KS / GRP;                 // groups per panel
     constexpr int PPG = GRP / WIDE_WAVES;         // DMA pieces per wave per group
-    constexpr int DSTEP = GRP / PPG;              // a piece is issued every DSTEP blocks
+    static_assert(GRP / PPG == 4, "one DMA piece per quad of blocks");
     constexpr int KREG = KS - KLDS;               // k-steps of a tile resident in registers; the last KLDS sit in LDS
 
     v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][GRP][64]
     int* cnt_all = reinterpret_cast<int*>(smem + NST * GRP * 1024);                   // [NQB]
     u64* cstage_all = reinterpret_cast<u64*>(cnt_all + NQB);                          // [WAVES][CAP+2]
-    v4u* qlds = reinterpret_cast<v4u*>(cstage_all + WIDE_WAVES * (CAP + 2)) + (size_t)wave * NT * KLDS * 64 + lane;   // [WAVES][NT][KLDS][64]
+    v4u* qlds_all = reinterpret_cast<v4u*>(cstage_all + WIDE_WAVES * (CAP + 2));     // [WAVES][NT][KLDS][64]
+    uint4* stg_all = reinterpret_cast<uint4*>(qlds_all + (size_t)WIDE_WAVES * NT * KLDS * 64);   // [WAVES][WIDE_STG] staging records
+    int* tail_all = reinterpret_cast<int*>(stg_all + (size_t)WIDE_WAVES * WIDE_STG);  // [WAVES]
+    v4u* qlds = qlds_all + (size_t)wave * NT * KLDS * 64 + lane;
+    uint4* stg = stg_all + (size_t)wave * WIDE_STG;
+    int* stg_tail = tail_all + wave;
     int* cnt_w = cnt_all + wave * NT * 32;
     u64* cstage = cstage_all + wave * (CAP + 2);
     for (int i = tid; i < NQB; i += WIDE_WAVES * 64) cnt_all[i] = 0;
@@ -562,12 +656,14 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
     // the VGPR half of the file, and hipcc then shuttles them through v_accvgpr_read in front of every MFMA.)
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
 
-    // panels of this workgroup: s in [s0, s1) of the (sampled) panel sequence, actual panel s * pstride
+    // panels of this workgroup: s in [s0, s1) of the (sampled) panel sequence; panel_of(s) is the corpus panel
     const int nb = gridDim.x;
-    const int pstride = P.sample_waves > 0 ? P.sample_stride : 1;
+    const int clog = P.sample_waves > 0 ? P.sample_chunk_log2 : 0;
+    const int cstride = P.sample_waves > 0 ? P.sample_stride : 1;
     const int S = P.sample_waves > 0 ? P.sample_waves : P.npanels;
     const int s0 = (int)(((long long)blockIdx.x * S) / nb);
     const int s1 = (int)(((long long)(blockIdx.x + 1) * S) / nb);
+    auto panel_of = [&](int s) -> unsigned { return (unsigned)(s >> clog) * (unsigned)cstride + (unsigned)(s & ((1 << clog) - 1)); };
 
     float rmin[NT], rmax[NT], tau_f[NT];
     u64 tau_key[NT];
@@ -588,9 +684,9 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
     __syncthreads();
 
     if (s1 > s0) {
-        const unsigned long long pbytes = (unsigned long long)pstride * KS * 1024ull;          // bytes between scanned panels
         const char* cbase = reinterpret_cast<const char*>(P.corpus);
-        const char* last_group = cbase + (unsigned long long)(s1 - 1) * pbytes + (GPP - 1) * GRP * 1024;
+        auto panel_src = [&](int s) -> const char* { return cbase + (unsigned long long)panel_of(s) * (KS * 1024ull); };   // wave-uniform
+        const char* last_group = panel_src(s1 - 1) + (GPP - 1) * GRP * 1024;
         const unsigned voff = (unsigned)lane * 16u + (unsigned)wave * 1024u;                    // piece j of wave w = block j*WAVES + w of its group
         const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u;
         // one DMA piece: 1 KiB from (wave-uniform base + voff) to LDS byte address dst
@@ -603,7 +699,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
 #pragma unroll
         for (int d = 0; d < NST - 1; ++d) {
             const int dp = s0 + d / GPP;
-            const char* src = dp < s1 ? cbase + (unsigned long long)dp * pbytes + (d % GPP) * GRP * 1024 : last_group;
+            const char* src = dp < s1 ? panel_src(dp) + (d % GPP) * GRP * 1024 : last_group;
 #pragma unroll
             for (int j = 0; j < PPG; ++j) dma_piece(src + j * WIDE_WAVES * 1024, lds_base + (unsigned)(d * GRP + j * WIDE_WAVES) * 1024u);
         }
@@ -611,75 +707,100 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
         // group g+1, so the LDS read-ahead never has to stop at a group or panel boundary
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 2)) : "memory");
         int st = 0;                                   // stage holding the current group
+        int st_new = 0, st_old = 0;                   // store instructions this wave issued in the last / second-to-last epilogue
         const v4u* buf = stage_lds + lane;            // current stage, this lane's slot
         v4u a[ADEPTH];
 #pragma unroll
         for (int u = 0; u < ADEPTH; ++u) a[u] = buf[u * 64];
 
-        const char* pbase = cbase + (unsigned long long)s0 * pbytes;     // panel s (wave-uniform)
         for (int s = s0; s < s1; ++s) {
             f32x16 acc[NT];
 #pragma unroll
             for (int g = 0; g < GPP; ++g) {
-                if constexpr (ABL == 2 || ABL == 6) asm volatile("s_barrier" ::: "memory");
-                else if constexpr (ABL == 7) {}
-                else if constexpr (ABL == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPG * (NST - 3)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PPG * (NST - 3)) : "memory");
+                // the DMA pieces of group g+1 were issued NST-2 groups (two panels) ago: the store instructions of the
+                // last two epilogues are younger than they are
+                if constexpr (ABL != 2 && ABL != 6 && ABL != 7) wide_wait_group<PPG * (NST - 3)>(st_new + st_old);
+                if constexpr (ABL != 5 && ABL != 7) asm volatile("s_barrier" ::: "memory");
                 // prefetch cursor: group g + NST-1 of the stream, into the stage everybody just left
-                constexpr int dgi_dummy = 0; (void)dgi_dummy;
                 const int dps = s + (g + NST - 1) / GPP;
-                const char* dsrc = dps < s1 ? pbase + (unsigned long long)((g + NST - 1) / GPP) * pbytes + ((g + NST - 1) % GPP) * GRP * 1024 : last_group;
+                const char* dsrc = dps < s1 ? panel_src(dps) + ((g + NST - 1) % GPP) * GRP * 1024 : last_group;
                 const unsigned ddst = lds_base + (unsigned)(st == 0 ? NST - 1 : st - 1) * (GRP * 1024u);
                 const int stn = st + 1 == NST ? 0 : st + 1;
                 const v4u* bufn = stage_lds + (size_t)stn * GRP * 64 + lane;
+                // Issue order inside a quad of four blocks: the four MFMAs of tile 0, then the four of tile 1 (each tile's
+                // own chain stays in k order).  Alternating the two accumulators MFMA by MFMA is the slowest pattern the
+                // matrix pipe has (tools/probe/mfma_probe.hip: 1.45 PFLOP/s chip-wide against 1.83 for runs of four).
 #pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    if (ABL != 2 && ABL != 6 && ABL != 7 && u % DSTEP == 0) dma_piece(dsrc + (u / DSTEP) * WIDE_WAVES * 1024, ddst + (unsigned)(u / DSTEP) * WIDE_WAVES * 1024u);
-                    const v4u a_use = a[u % ADEPTH];
+                for (int qd = 0; qd < GRP / 4; ++qd) {
+                    if (ABL != 2 && ABL != 6 && ABL != 7) dma_piece(dsrc + qd * WIDE_WAVES * 1024, ddst + (unsigned)qd * WIDE_WAVES * 1024u);
                     __builtin_amdgcn_sched_barrier(0);
-                    const int ks = g * GRP + u;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        // register file of the resident B-operand: tile 0 in VGPRs, tile 1 in AGPRs (NT = 2);
-                        // first / second half of the k-steps (NT = 1).  The accumulators are AGPRs.
-                        const int ab = NT == 2 ? t : (ks >= KS / 2 ? 1 : 0);
-                        if constexpr (ABL == 1) {
-                            if (ab) asm volatile("" ::"v"(a_use), "a"(qreg[t][ks < KREG ? ks : 0]));
-                            else asm volatile("" ::"v"(a_use), "v"(qreg[t][ks < KREG ? ks : 0]));
-                            if (ks == 0) asm volatile("" : "=a"(acc[t]));
-                        } else
-                        if (ks < KREG) {
-                            CmrBlk<DT>::mma_asm(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
-                        } else {
-                            const v4u b = qlds[(t * KLDS + (ks < KREG ? 0 : ks - KREG)) * 64];
-                            CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int u = qd * 4 + j;
+                            const int ks = g * GRP + u;
+                            const v4u a_use = a[u % ADEPTH];
+                            // register file of the resident B-operand: tile 0 in VGPRs, tile 1 in AGPRs (NT = 2); first /
+                            // second half of the k-steps (NT = 1).  The accumulators are AGPRs.
+                            // (WIDE_AMOVE of tile 0's operands also sit in AGPRs: the AGPR half has registers to spare)
+                            const int ab = NT == 2 ? (t == 1 || ks >= KS - WIDE_AMOVE ? 1 : 0) : (ks >= KS / 2 ? 1 : 0);
+                            if constexpr (ABL == 1) {
+                                if (ab) asm volatile("" ::"v"(a_use), "a"(qreg[t][ks < KREG ? ks : 0]));
+                                else asm volatile("" ::"v"(a_use), "v"(qreg[t][ks < KREG ? ks : 0]));
+                                if (ks == 0) asm volatile("" : "=a"(acc[t]));
+                            } else if (ks < KREG) {
+                                CmrBlk<DT>::mma_asm(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
+                            } else {
+                                const v4u b = qlds[(t * KLDS + (ks < KREG ? 0 : ks - KREG)) * 64];
+                                CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
+                            }
+                        }
+                    // the quad's four ring slots take the blocks ADEPTH ahead (they land under the next quad's MFMAs)
+                    if constexpr (ABL != 6) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int blk = qd * 4 + j + ADEPTH;
+                            a[(qd * 4 + j) % ADEPTH] = blk < GRP ? buf[blk * 64] : bufn[(blk - GRP) * 64];
                         }
                     }
-                    if constexpr (ABL != 6) a[u % ADEPTH] = u + ADEPTH < GRP ? buf[(u + ADEPTH) * 64] : bufn[(u + ADEPTH - GRP) * 64];
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 st = stn;
                 buf = bufn;
             }
-            pbase += pbytes;
             cmr_mfma_drain<NT>(acc);          // MFMA results -> VALU readers: wait states hipcc does not insert for asm
             if constexpr (ABL == 3) continue;
 
-            const unsigned row0 = (unsigned)s * (unsigned)pstride * CMR_PANEL_ROWS;     // < 2^32 rows per shard (cmr_index_append)
+            const unsigned row0 = panel_of(s) * CMR_PANEL_ROWS;                         // < 2^32 rows per shard (cmr_index_append)
             int nvalid = CMR_PANEL_ROWS;
             const bool partial = (long long)row0 + CMR_PANEL_ROWS > P.nrows;            // only the corpus' last panel
             if (__builtin_expect(partial, 0)) {
                 nvalid = (int)(P.nrows - (long long)row0);
                 asm volatile("" : "+s"(nvalid));      // keeps the masked variant's arithmetic inside this branch
             }
+            int n_stores = 0;
+            bool compacted = false;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const float mx = __builtin_expect(partial, 0) ? wide_minmax_partial(acc[t], nvalid, lane, rmin[t], rmax[t])
                                                               : wide_minmax(acc[t], rmin[t], rmax[t]);
                 if (ABL != 4 && __any(mx >= tau_f[t])) {
-                    const u64 need = wide_push<CAP>(acc[t], row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane);
-                    if (need) wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
+                    // sampling pass: dense hits (threshold from a small sample) -> staged push; main pass: sparse hits
+                    const u64 need = P.sample_waves > 0
+                        ? wide_push<CAP>(acc[t], row0, nvalid, tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, stg, stg_tail, lane, n_stores)
+                        : wide_push_sparse<CAP>(acc[t], row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane, n_stores);
+                    if (need) {
+                        wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
+                        compacted = true;
+                    }
                 }
+            }
+            st_old = st_new;
+            st_new = __builtin_amdgcn_readfirstlane(n_stores);
+            if (compacted) {        // its loads already drained the ring; retire its stores too and restart the count
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_old = st_new = 0;
             }
         }
     }
@@ -709,7 +830,7 @@ size_t cmr_wide_lds_bytes(int ks, int cap) {
     const int nst = ks == 48 ? WIDE_NST_48 : WIDE_NST_64;
     const int klds = ks == 48 ? WIDE_KLDS_48 : WIDE_KLDS_64;
     return (size_t)nst * WIDE_GROUP * 1024 + (size_t)WIDE_WAVES * nt * 32 * 4 + (size_t)WIDE_WAVES * (cap + 2) * 8 +
-           (size_t)WIDE_WAVES * nt * klds * 1024;
+           (size_t)WIDE_WAVES * nt * klds * 1024 + (size_t)WIDE_WAVES * WIDE_STG * 16 + WIDE_WAVES * 4;
 }
 
 // wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 4 waves x 2 tiles x 32 = 256 queries per pass),

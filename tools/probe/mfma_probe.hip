@@ -3,6 +3,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_probe mfma_probe.hip && ./mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
+#include <cstring>
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned v4u;
 
@@ -26,10 +28,14 @@ __global__ __launch_bounds__(256, 1) void probe(const v4u* in, float* out, long 
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));            \
     if (FILL == 1) asm volatile("s_nop 0");                                                              \
     if (FILL == 2) asm volatile("v_mov_b32 %0, %0" : "+v"(a.x));
+            if (CH == 22) { MF(c0, b0) MF(c0, b2) MF(c1, b1) MF(c1, b3) }                 // two chains, pairs back to back
+            else if (CH == 24) { MF(c0, b0) MF(c0, b2) MF(c0, b0) MF(c0, b2) MF(c1, b1) MF(c1, b3) MF(c1, b1) MF(c1, b3) }
+            else {
             MF(c0, b0)
             if (CH >= 2) { MF(c1, b1) }
             if (CH >= 3) { MF(c2, b2) }
             if (CH >= 4) { MF(c3, b3) }
+            }
         }
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(c0), "+a"(c1), "+a"(c2), "+a"(c3));
@@ -51,16 +57,29 @@ void run(const char* name, const v4u* in, float* out, long long* cyc) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     long long h; hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
-    const double n = (double)iters * 12 * CH;
+    const double n = (double)iters * 12 * (CH == 22 ? 4 : CH == 24 ? 8 : CH);
     printf("%-44s chains %d B-in-%s fill %d: %.1f s_memtime ticks / MFMA, %.2f ns / MFMA (wall), %.0f TFLOP/s chip\n", name, CH, AB ? "AGPR" : "VGPR", FILL,
            (double)h / n, ms * 1e6 / n, 2.0 * 32 * 32 * 16 * n * 1024 / (ms * 1e-3) / 1e12);
 }
 
-int main() {
+int main(int argc, char** argv) {
     v4u* in; float* out; long long* cyc;
     hipMalloc(&in, 320 * 16); hipMalloc(&out, 256 * 256 * 4); hipMalloc(&cyc, 8);
     unsigned short h[320 * 8];
-    for (int i = 0; i < 320 * 8; ++i) h[i] = 0x3c00 + (i * 2654435761u >> 20 & 0x3ff);   // random-ish bf16 around 0.01
+    // operand values: argv[1] = "unit" -> bf16 of N(0, 1/768) components (what a normalised 768-d corpus holds: random sign,
+    // exponent and mantissa bits); default -> values near 1.0 with random low mantissa bits (little toggling)
+    const bool unit = argc > 1 && argv[1][0] == 'u';
+    unsigned long long st = 88172645463325252ull;
+    for (int i = 0; i < 320 * 8; ++i) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+        if (unit) {
+            double u1 = ((st >> 11) + 1) / 9007199254740993.0; st ^= st << 13; st ^= st >> 7; st ^= st << 17;
+            double u2 = (st >> 11) / 9007199254740992.0;
+            float f = (float)(sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2) / sqrt(768.0));
+            unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+        } else h[i] = 0x3c00 + (unsigned short)(st & 0x3ff);
+    }
+    printf("operands: %s\n", unit ? "N(0, 1/768) bf16" : "~1.0 bf16");
     hipMemcpy(in, h, sizeof(h), hipMemcpyHostToDevice);
     run<1, 0, 0>("1 chain back-to-back", in, out, cyc);
     run<1, 0, 1>("1 chain + s_nop between", in, out, cyc);
@@ -68,6 +87,9 @@ int main() {
     run<2, 1, 0>("2 chains, B in AGPR", in, out, cyc);
     run<2, 0, 1>("2 chains + s_nop after each", in, out, cyc);
     run<2, 0, 2>("2 chains + VALU after each", in, out, cyc);
+    run<22, 0, 0>("2 chains, AABB order", in, out, cyc);
+    run<22, 1, 0>("2 chains, AABB order, B in AGPR", in, out, cyc);
+    run<24, 0, 0>("2 chains, AAAABBBB order", in, out, cyc);
     run<3, 0, 0>("3 chains", in, out, cyc);
     run<3, 0, 1>("3 chains + s_nop after each", in, out, cyc);
     run<4, 0, 0>("4 chains", in, out, cyc);
