@@ -51,9 +51,13 @@ def _matrix_index(mat, dtype: str, device: int) -> Optional[DenseIndex]:
     return idx
 
 
-def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True):
+def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True, index_factory=None):
+    """`index_factory(matrix, dtype, device) -> index` builds the HBM mirror of a host matrix (default: a `DenseIndex`
+    filled with `append`); anything with DenseIndex's `scores` / `search` / `sorted_scores` / `__len__` serves — the
+    CPU-tier binding tests pass a numpy stand-in there to exercise this glue on the real reference classes without a GPU."""
     cfg = getattr(rag, "global_config", None)
     dtype = index_dtype or getattr(cfg, "index_dtype", None) or "f32"
+    make_index = index_factory or _matrix_index
     lock = threading.Lock()
     orig_prepare = rag.prepare_retrieval_objects
     rag._hip = {"passage": None, "summary": None, "fact": None, "dtype": dtype}
@@ -63,10 +67,10 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
             if getattr(self, "ready_to_retrieve", False) and self._hip["passage"] is not None:
                 return
             orig_prepare()
-            self._hip["passage"] = _matrix_index(self.passage_embeddings, dtype, device)
-            self._hip["fact"] = _matrix_index(self.fact_embeddings, dtype, device)
+            self._hip["passage"] = make_index(self.passage_embeddings, dtype, device)
+            self._hip["fact"] = make_index(self.fact_embeddings, dtype, device)
             if getattr(self.global_config, "need_cluster", False) and hasattr(self, "summary_embeddings"):
-                self._hip["summary"] = _matrix_index(self.summary_embeddings, dtype, device)
+                self._hip["summary"] = make_index(self.summary_embeddings, dtype, device)
 
     def _query_vec(self, kind: str, query: str, instruction_key: str):
         vec = self.query_to_embedding[kind].get(query, None)
@@ -108,7 +112,7 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
     return rag
 
 
-def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0):
+def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0, index_factory=None):
     """Rebind `MemoryPool.retrieve_similar_nodes` (utils/memory_utils.py:188-235) on ONE pool
     instance: node embeddings live in an appendable HBM index (rows = pool order; nodes added since
     the last call are encoded with the reference's own `compute_probe_note_embeddings` and appended —
@@ -134,8 +138,8 @@ def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0):
             if fresh:
                 mat = np.stack([_to_np(n.embedding) for _, n in fresh])
                 mat = mat / np.maximum(np.linalg.norm(mat, axis=1, keepdims=True), 1e-12)   # cosine == dot of unit rows
-                if state["index"] is None:
-                    state["index"] = DenseIndex(mat.shape[1], index_dtype, device=device)
+                if state["index"] is None:      # index_factory(dim, dtype, device): test seam, as in install()
+                    state["index"] = index_factory(mat.shape[1], index_dtype, device) if index_factory else DenseIndex(mat.shape[1], index_dtype, device=device)
                 state["index"].append(mat)
                 state["rows"].extend(i for i, _ in fresh)
             if state["index"] is None:

@@ -173,7 +173,11 @@ def main():
         obj.query_to_embedding = {"triple": {}, "passage": {}}
         obj.embedding_model = emb
         out = {"doc_md5": [orc.compute_mdhash_id(d) for d in docs], "n_docs": len(docs),
-               "keys": keys, "questions": [], "top5_ids": [], "top5_scores": []}
+               "keys": keys, "questions": [], "top5_ids": [], "top5_scores": [],
+               # the fake embedder's vectors of the six chunks / three questions, so the GPU tier (no reference tree,
+               # hence no chunk texts) can rebuild the same index
+               "doc_vecs": np.array(cs.get_embeddings(keys)).tolist(),
+               "question_vecs": [emb._vec(qa["question"]).tolist() for qa in qas]}
         for qa in qas:
             q = qa["question"]
             ids_, sc_ = obj.dense_passage_retrieval(q)

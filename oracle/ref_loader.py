@@ -43,8 +43,9 @@ def _stub(name: str) -> types.ModuleType:
     return m
 
 
-def load_reference():
-    """Returns the imported ``src.comorag`` package of the reference."""
+def prepare_stubs():
+    """Install the stubs and put the reference tree on sys.path WITHOUT importing it — for callers that alias modules
+    first (comorag_amd.hooks.patch_reference_modules must run before ``src.comorag.ComoRAG`` is imported)."""
     if not reference_available():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
     sys.dont_write_bytecode = True
@@ -61,6 +62,11 @@ def load_reference():
         ten.retry = lambda *a, **k: (lambda f: f)  # decorator passthrough
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
+
+
+def load_reference():
+    """Returns the imported ``src.comorag`` package of the reference."""
+    prepare_stubs()
     return importlib.import_module("src.comorag")
 
 

@@ -65,3 +65,44 @@ class FakeEmbedder:
 @pytest.fixture
 def fake_embedder():
     return FakeEmbedder(32)
+
+
+class NumpyIndex:
+    """numpy stand-in with DenseIndex's call surface (append / scores / search / sorted_scores / len / close), fp32,
+    exported tie rule.  TEST INFRASTRUCTURE: lets the CPU tier drive the binding glue (comorag_amd.hooks, retrieval.*)
+    on the real reference classes; the product never sees it."""
+
+    def __init__(self, dim, dtype="f32", device=0, **kw):
+        self.dim, self.dtype, self.device = dim, dtype, device
+        self._x = np.empty((0, dim), np.float32)
+
+    def append(self, rows):
+        rows = np.asarray(rows, np.float32).reshape(-1, self.dim)
+        self._x = np.concatenate([self._x, rows])
+
+    def __len__(self):
+        return len(self._x)
+
+    def close(self):
+        pass
+
+    def scores(self, q):
+        q = np.asarray(q, np.float32).reshape(-1, self.dim)
+        return (q @ self._x.T).astype(np.float32)
+
+    def search(self, q, k, with_minmax=True):
+        s = self.scores(q)
+        k = min(k, s.shape[1])
+        ids = np.stack([np.lexsort((np.arange(s.shape[1]), -r))[:k] for r in s])
+        sc = np.take_along_axis(s, ids, axis=1)
+        return ids.astype(np.int64), sc, (s.min(1) if with_minmax else None), (s.max(1) if with_minmax else None)
+
+    def sorted_scores(self, q):
+        s = self.scores(q)
+        ids = np.stack([np.lexsort((np.arange(s.shape[1]), -r)) for r in s])
+        return ids.astype(np.int64), np.take_along_axis(s, ids, axis=1), s.min(1), s.max(1)
+
+
+@pytest.fixture
+def numpy_index_cls():
+    return NumpyIndex

@@ -1,0 +1,192 @@
+"""The binding glue (comorag_amd/hooks.py, embedding_store.py, retrieval.py) on the REAL reference classes — CPU tier.
+
+Needs the reference tree (this container; the GPU box has none, tests skip there — its twins with the HIP index are in
+tests/test_dropin_gpu.py).  The device index is replaced by conftest.NumpyIndex through the hooks' `index_factory`
+seam, so what is tested here is exactly the glue: which names get rebound, on which objects, with which semantics.
+    ComoRAG.py:92-124   five stores + embedding-model factory          (module aliasing)
+    ComoRAG.py:876-967  prepare_retrieval_objects / get_query_embeddings / get_fact_scores / dense_passage_retrieval
+    utils/memory_utils.py:149-235  MemoryPool.compute_probe_note_embeddings / retrieve_similar_nodes
+    main_openai.py:8-44 → BASELINE config 1 (cinderella, fake embedder): index + dense retrieval top-5
+"""
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from oracle.ref_loader import REFERENCE_ROOT, reference_available
+
+pytestmark = pytest.mark.skipif(not reference_available(), reason="reference tree not present")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_patch_reference_modules_binds_the_real_comorag_module():
+    """alias the three replaced modules, THEN import the reference's ComoRAG.  Runs in a fresh
+    interpreter (module aliasing is process-global)."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from oracle import ref_loader
+ref_loader.prepare_stubs()
+from comorag_amd import hooks, embedding_store, embedding_model, retrieval
+hooks.patch_reference_modules("src.comorag")
+import importlib
+C = importlib.import_module("src.comorag.ComoRAG")
+assert C.EmbeddingStore is embedding_store.EmbeddingStore, C.EmbeddingStore
+assert C._get_embedding_model_class is embedding_model._get_embedding_model_class
+assert C.retrieve_knn is retrieval.retrieve_knn
+tl = importlib.import_module("src.comorag.utils.timeline_utils")        # the other EmbeddingStore consumer
+assert tl.EmbeddingStore is embedding_store.EmbeddingStore
+assert getattr(tl, "get_similar_summaries", retrieval.get_similar_summaries) is retrieval.get_similar_summaries
+# untouched: everything else is still the reference's
+assert C.ComoRAG.__module__ == "src.comorag.ComoRAG" and C.MemoryPool.__module__ == "src.comorag.utils.memory_utils"
+print("BOUND")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1", "COMORAG_HIP_NO_TORCH": "1"})
+    assert r.returncode == 0 and "BOUND" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _stores(tmp_path, emb, Store):
+    chunks = [f"chunk {i}: " + w for i, w in enumerate(["cinders", "a glass slipper", "the ball at midnight", "two stepsisters",
+                                                         "a pumpkin coach", "the prince's search", "a hazel tree", "white doves"])]
+    ents = ["cinderella", "prince", "stepmother", "slipper", "pumpkin"]
+    facts = [str(t) for t in [("cinderella", "lost", "slipper"), ("prince", "found", "slipper"), ("stepmother", "hid", "cinderella"),
+                              ("pumpkin", "became", "coach"), ("doves", "helped", "cinderella"), ("prince", "married", "cinderella")]]
+    sums = ["summary: the ball", "summary: the search", "summary: the wedding"]
+    out = {}
+    for ns, texts in (("chunk", chunks), ("entity", ents), ("fact", facts), ("summary", sums)):
+        st = Store(emb, str(tmp_path / f"{ns}_{Store.__module__.split('.')[0]}"), 8, ns)
+        st.insert_strings(texts)
+        out[ns] = st
+    return out
+
+
+def _bare_rag(ComoRAG, stores, emb):
+    """A real ComoRAG instance without its constructor (LLM clients, igraph): only what :876-967 read."""
+    rag = ComoRAG.__new__(ComoRAG)
+    rag.global_config = types.SimpleNamespace(need_cluster=True, index_dtype="f32")
+    rag.embedding_model = emb
+    rag.ver_embedding_store, rag.entity_embedding_store = stores["chunk"], stores["entity"]
+    rag.fact_embedding_store, rag.sem_embedding_store = stores["fact"], stores["summary"]
+    names = stores["entity"].get_all_ids() + stores["chunk"].get_all_ids()
+    rag.graph = types.SimpleNamespace(vs=[{"name": n} for n in names])        # igraph's vertex sequence, as far as :889 goes
+    rag.ready_to_retrieve = False
+    return rag
+
+
+def test_install_on_a_real_comorag_instance(tmp_path, fake_embedder, numpy_index_cls):
+    from oracle.ref_loader import ref_modules
+    m = ref_modules()
+    ComoRAG = m["ComoRAG"].ComoRAG
+    from comorag_amd import hooks
+    from comorag_amd.embedding_store import EmbeddingStore
+
+    built = []
+
+    def factory(mat, dtype, device):
+        mat = np.asarray(mat, np.float32)
+        if mat.ndim != 2 or len(mat) == 0:
+            return None
+        ix = numpy_index_cls(mat.shape[1], dtype, device)
+        ix.append(mat)
+        built.append(ix)
+        return ix
+
+    ours = _bare_rag(ComoRAG, _stores(tmp_path, fake_embedder, EmbeddingStore), fake_embedder)
+    ref = _bare_rag(ComoRAG, _stores(tmp_path, fake_embedder, m["embedding_store"].EmbeddingStore), fake_embedder)
+    hooks.install(ours, index_factory=factory, patch_module_functions=False)
+    assert ours.prepare_retrieval_objects.__func__.__module__ == "comorag_amd.hooks"
+    ours.prepare_retrieval_objects()                 # runs the reference's own :876-907 inside, then builds the indexes
+    ours.prepare_retrieval_objects()                 # once only
+    ref.prepare_retrieval_objects()
+    assert len(built) == 3 and ours.ready_to_retrieve
+    assert ours.passage_node_keys == ref.passage_node_keys and ours.fact_node_keys == ref.fact_node_keys
+    assert np.array_equal(ours.passage_embeddings, ref.passage_embeddings) and np.array_equal(ours.fact_embeddings, ref.fact_embeddings)
+    assert ours.passage_node_idxs == ref.passage_node_idxs
+    for q in ["who lost a slipper?", "what became a coach?", "who helped cinderella?"]:
+        n0 = len(fake_embedder.calls)
+        ours.get_query_embeddings(q)                 # tri_retrieve passes a str (:470): encoded once per kind, not per character
+        assert fake_embedder.calls[n0:] == [[q], [q]]
+        a_ids, a_sc = ours.dense_passage_retrieval(q)
+        assert len(fake_embedder.calls) == n0 + 2    # memoised
+        b_ids, b_sc = ref.dense_passage_retrieval(q)
+        assert a_ids.tolist() == b_ids.tolist()
+        np.testing.assert_allclose(a_sc, b_sc, atol=2e-6)
+        np.testing.assert_allclose(ours.get_fact_scores(q), ref.get_fact_scores(q), atol=2e-6)
+        c_ids, c_sc = ours.dense_passage_retrieval(q, need_cluster=True)
+        d_ids, d_sc = ref.dense_passage_retrieval(q, need_cluster=True)
+        assert c_ids.tolist() == d_ids.tolist()
+        np.testing.assert_allclose(c_sc, d_sc, atol=2e-6)
+
+
+def test_install_memory_pool_on_a_real_pool(fake_embedder, numpy_index_cls):
+    """BASELINE config 4's shape on the reference's own MemoryPool: three cycles of (add nodes, retrieve); the rebound
+    method must select the nodes the reference method selects on an identical pool, appending only the new rows."""
+    from oracle.ref_loader import ref_modules
+    mu = ref_modules()["memory_utils"]
+    from comorag_amd import hooks
+
+    def mk():
+        return mu.MemoryPool(embedding_model=fake_embedder, agent=None)
+
+    ours, ref = mk(), mk()
+    appended = []
+
+    class Ix(numpy_index_cls):
+        def append(self, rows):
+            appended.append(len(np.asarray(rows).reshape(-1, self.dim)))
+            super().append(rows)
+
+    hooks.install_memory_pool(ours, index_factory=lambda dim, dtype, device: Ix(dim, dtype, device))
+    assert ours.retrieve_similar_nodes.__func__.__module__ == "comorag_amd.hooks"
+    cue = 0
+    for cycle, probe in enumerate(["where is the slipper?", "who is the stepmother?", "what happened at midnight?"]):
+        for pool in (ours, ref):
+            c = cue
+            for kind in (mu.NodeType.VER, mu.NodeType.SEM, mu.NodeType.EPI):
+                for j in range(2):
+                    pool.add_to_temp_pool(mu.MemoryNode(probe=probe, node_type=kind, original_content=[f"text {c}"], cue=f"cue number {c}"))
+                    c += 1
+            if cycle == 1:          # identical content twice: equal similarity, the stable sort keeps pool order
+                pool.add_to_temp_pool(mu.MemoryNode(probe=probe, node_type=mu.NodeType.SEM, original_content=["dup"], cue=f"cue number {cue}"))
+            pool.merge_temp_to_main()
+        cue = c
+        for pct in (0.5, 0.2, 1.0):
+            a = ours.retrieve_similar_nodes(probe, top_percent=pct)
+            b = ref.retrieve_similar_nodes(probe, top_percent=pct)
+            assert [ours.pool.index(n) for n in a] == [ref.pool.index(n) for n in b], (cycle, pct)
+        ours.add_fused_node(probe, f"fused note {cycle}", a); ref.add_fused_node(probe, f"fused note {cycle}", b)
+        ours.merge_temp_to_main(); ref.merge_temp_to_main()
+    assert appended == [6, 8, 7] and len(ours._hip_state["rows"]) == len(ours.pool) - 1      # the last fused node is not indexed yet
+
+
+def test_config1_cinderella_plumbing(tmp_path, golden_dir, fake_embedder, numpy_index_cls):
+    """BASELINE config 1: the cinderella corpus through OUR EmbeddingStore (md5 ids, dedup, order) and OUR
+    dense_passage_retrieval; ids and normalised scores must be the ones the reference produced (tests/golden/
+    cinderella.json: reference store + reference ComoRAG.dense_passage_retrieval, oracle/make_golden.py)."""
+    from comorag_amd import retrieval
+    from comorag_amd.embedding_store import EmbeddingStore
+    c = json.load(open(os.path.join(golden_dir, "cinderella.json")))
+    cdir = os.path.join(REFERENCE_ROOT, "dataset", "cinderella", "cinderella_1")
+    docs = [json.loads(l)["contents"] for l in open(os.path.join(cdir, "corpus.jsonl"), encoding="utf-8") if l.strip()]   # main_openai.py:13-19
+    st = EmbeddingStore(fake_embedder, str(tmp_path / "cinder"), 8, "cinder")
+    st.insert_strings(docs)
+    st.insert_strings(docs[:2])                                    # re-insert: nothing new
+    keys = st.get_all_ids()
+    assert keys == c["keys"] and len(keys) == c["n_docs"]
+    rows = np.asarray(st.get_embeddings(keys), np.float32)
+    np.testing.assert_array_equal(rows, np.asarray(c["doc_vecs"], np.float32))
+    ix = numpy_index_cls(rows.shape[1]); ix.append(rows)
+    for q, want_ids, want_sc, qv in zip(c["questions"], c["top5_ids"], c["top5_scores"], c["question_vecs"]):
+        vec = fake_embedder.batch_encode(q)
+        np.testing.assert_array_equal(vec[0], np.asarray(qv, np.float32))
+        ids, sc = retrieval.dense_passage_retrieval(ix, vec)
+        assert ids[:5].tolist() == want_ids
+        np.testing.assert_allclose(sc[:5], want_sc, atol=2e-6)
+        tid, tsc = retrieval.dense_passage_topk(ix, vec, 5)
+        assert tid[0].tolist() == want_ids
+        np.testing.assert_allclose(tsc[0], want_sc, atol=2e-6)

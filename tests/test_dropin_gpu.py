@@ -55,9 +55,61 @@ def test_store_device_mirror_summaries_and_cinderella(golden_dir, tmp_path, fake
     texts, scores = retrieval.get_similar_summaries(s["query"], lv, fake_embedder, top_k=3)
     assert texts == s["top_texts"] and fake_embedder.calls == s["encode_calls"]
     np.testing.assert_allclose(scores, s["top_scores"], atol=2e-6)
-    # BASELINE config 1: cinderella chunks (fixture carries the md5 of each chunk; texts are not shipped)
+
+
+def test_config1_cinderella_on_the_hip_index(golden_dir):
+    """BASELINE config 1 on the GPU: the six cinderella chunks' vectors (fixture: the fake embedder's outputs the
+    reference store held; the chunk texts live in the reference tree only) in an f32 DenseIndex; the complete ranking
+    and the top-5 of each question must be the reference's (ComoRAG.dense_passage_retrieval, oracle/make_golden.py).
+    The CPU-tier twin with the real texts through EmbeddingStore is tests/test_binding_reference.py."""
+    from comorag_amd import retrieval
+    from comorag_amd.index import DenseIndex
     c = json.load(open(os.path.join(golden_dir, "cinderella.json")))
-    assert len(c["keys"]) == 6
+    X = np.asarray(c["doc_vecs"], np.float32)
+    assert X.shape[0] == c["n_docs"] == len(c["keys"]) == 6
+    ix = DenseIndex(X.shape[1], "f32"); ix.append(X)
+    for want_ids, want_sc, qv in zip(c["top5_ids"], c["top5_scores"], c["question_vecs"]):
+        q = np.asarray(qv, np.float32)[None]
+        ids, sc = retrieval.dense_passage_retrieval(ix, q)
+        assert ids[:5].tolist() == want_ids and len(ids) == 6
+        np.testing.assert_allclose(sc[:5], want_sc, atol=2e-6)
+        tid, tsc = retrieval.dense_passage_topk(ix, q, 5)
+        assert tid[0].tolist() == want_ids
+        np.testing.assert_allclose(tsc[0], want_sc, atol=2e-6)
+    ix.close()
+
+
+def test_install_memory_pool_on_a_pool_shaped_object(fake_embedder):
+    """GPU twin of tests/test_binding_reference.py::test_install_memory_pool_on_a_real_pool: append-then-search on the
+    HIP index behind MemoryPool.retrieve_similar_nodes, against the reference's python loop restated in the oracle."""
+    from comorag_amd import hooks
+
+    class Node:
+        def __init__(self, probe, cue):
+            self.probe, self.cue, self.embedding = probe, cue, None
+
+    class Pool:                                  # utils/memory_utils.py:149-186 as far as the hook reads it
+        def __init__(self, em):
+            self.pool, self.embedding_model = [], em
+        def compute_probe_note_embeddings(self):
+            todo = [n for n in self.pool if n.embedding is None]
+            if todo:
+                for n, e in zip(todo, self.embedding_model.encode([f"{n.probe} {n.cue}" for n in todo]).numpy()):
+                    n.embedding = e
+
+    pool = hooks.install_memory_pool(Pool(fake_embedder))
+    for cycle in range(3):
+        for j in range(5):
+            pool.pool.append(Node(f"probe {cycle}", f"cue {cycle}-{j}"))
+        if cycle == 1:
+            pool.pool.append(Node("probe 1", "cue 1-0"))           # duplicate content: pool order decides
+        for pct in (0.5, 0.25, 1.0):
+            got = pool.retrieve_similar_nodes(f"probe {cycle}", top_percent=pct)
+            embs = [n.embedding for n in pool.pool]
+            want = orc.retrieve_similar_nodes(embs, fake_embedder._vec(f"probe {cycle}"), pct)
+            assert [pool.pool.index(n) for n in got] == want
+    assert len(pool._hip_state["index"]) == len(pool.pool) == 16
+    pool._hip_state["index"].close()
 
 
 def test_retrieve_knn_vs_reference_and_large_k(golden_dir):

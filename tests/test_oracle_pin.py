@@ -71,9 +71,17 @@ def test_insert_plan_matches_store_fixture(golden_dir):
 
 
 def test_cinderella_fixture(golden_dir, fake_embedder):
-    """BASELINE config 1 (plumbing, CPU): cinderella chunks → md5 ids → dense top-5, reference outputs."""
+    """BASELINE config 1 (plumbing, CPU): the ORACLE on the six cinderella chunk vectors must give the top-5 the
+    reference's store + dense_passage_retrieval gave (the product's run over the same data: tests/test_binding_reference.py
+    on CPU with the real texts, tests/test_dropin_gpu.py::test_config1_cinderella_on_the_hip_index on the GPU)."""
     c = json.load(open(os.path.join(golden_dir, "cinderella.json")))
     assert c["n_docs"] == 6 and c["keys"] == ["cinder-" + h for h in c["doc_md5"]]
+    X = np.asarray(c["doc_vecs"], np.float32)
+    for q, want_ids, want_sc, qv in zip(c["questions"], c["top5_ids"], c["top5_scores"], c["question_vecs"]):
+        np.testing.assert_array_equal(fake_embedder._vec(q), np.asarray(qv, np.float32))
+        ids, sc = orc.dense_passage_retrieval(X, np.asarray(qv, np.float32)[None])
+        assert ids[:5].tolist() == want_ids
+        np.testing.assert_allclose(sc[:5], want_sc, atol=1e-6)
 
 
 def test_live_reference_functions_agree():
