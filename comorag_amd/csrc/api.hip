@@ -172,12 +172,12 @@ Workspace* acquire_ws(cmr_index* idx, hipStream_t user_stream, bool dev_api) {
         idx->stream_ws[user_stream] = w;
         return w;
     }
-    if (dev_api) {  // NULL stream on the dev API: one dedicated own-stream workspace
+    if (dev_api) {  // NULL on the dev API is the legacy default stream itself (what torch's default stream is): work enqueued
+                    // there is ordered with the caller's kernels on that stream, exactly as on any other stream handle
         auto it = idx->stream_ws.find(nullptr);
         if (it != idx->stream_ws.end()) return it->second;
         Workspace* w = new Workspace();
-        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) { delete w; return nullptr; }
-        w->own_stream = true;
+        w->stream = nullptr;
         idx->stream_ws[nullptr] = w;
         return w;
     }
@@ -767,6 +767,35 @@ int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream
     return CMR_OK;
 }
 
+int32_t cmr_index_query_status(cmr_index_t* idx, int32_t* nonfinite) {
+    if (!idx || !nonfinite) return fail(CMR_ERR_INVALID, "NULL argument");
+    *nonfinite = 0;
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    std::vector<Workspace*> wss;
+    {
+        std::lock_guard<std::mutex> pl(idx->pipe_mu);
+        for (int i = 0; i < 2; ++i) if (idx->pipe.slot[i].used) wss.push_back(&idx->pipe.slot[i].ws);
+        if (idx->pipe.sp) { HIP_TRY(hipStreamSynchronize(idx->pipe.sp)); HIP_TRY(hipStreamSynchronize(idx->pipe.sm)); HIP_TRY(hipStreamSynchronize(idx->pipe.sq)); }
+    }
+    {
+        std::lock_guard<std::mutex> g(idx->ws_mu);
+        for (auto& kv : idx->stream_ws) wss.push_back(kv.second);
+    }
+    for (Workspace* ws : wss) {
+        if (!ws->flag.p) continue;
+        if (ws->stream || !ws->own_stream) HIP_TRY(hipStreamSynchronize(ws->stream));
+        int h = 0;
+        HIP_TRY(hipMemcpy(&h, ws->flag.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (h) {
+            *nonfinite = 1;
+            HIP_TRY(hipMemset(ws->flag.p, 0, sizeof(int)));
+        }
+    }
+    return CMR_OK;
+}
+
 int32_t cmr_stream_wait_event(void* stream, void* event) {
     if (!event) return CMR_OK;
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
@@ -896,7 +925,7 @@ int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const in
     HIP_TRY(ws->d_scores.ensure((size_t)nq * k * 4));
     HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ws->d_cand.p, cand, (size_t)nq * n_cand * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, (const float*)ws->d_q.p, nq,
+    HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, idx->id_base, (const float*)ws->d_q.p, nq,
                                (const int64_t*)ws->d_cand.p, n_cand, k, (int64_t*)ws->d_ids.p, (float*)ws->d_scores.p, s));
     HIP_TRY(hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
@@ -917,7 +946,7 @@ int32_t cmr_index_get_rows(cmr_index_t* idx, const int64_t* ids, int64_t n, floa
     HIP_TRY(ws->d_cand.ensure((size_t)n * 8));
     HIP_TRY(ws->d_out.ensure((size_t)n * idx->dim * 4));
     HIP_TRY(hipMemcpyAsync(ws->d_cand.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(cmr_launch_gather_rows(idx->dtype, idx->corpus, idx->dim, idx->dpad, idx->n, (const int64_t*)ws->d_cand.p, n,
+    HIP_TRY(cmr_launch_gather_rows(idx->dtype, idx->corpus, idx->dim, idx->dpad, idx->n, idx->id_base, (const int64_t*)ws->d_cand.p, n,
                                    (float*)ws->d_out.p, s));
     HIP_TRY(hipMemcpyAsync(out, ws->d_out.p, (size_t)n * idx->dim * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -665,24 +665,24 @@ __device__ __forceinline__ float cmr_load_elem(const unsigned char* corpus, int 
 
 template <int DT>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const unsigned char* __restrict__ corpus, int dim, int ks_total,
-                                                          long long nrows, const int64_t* __restrict__ ids, long long n,
+                                                          long long nrows, long long id_base, const int64_t* __restrict__ ids, long long n,
                                                           float* __restrict__ out) {
     const long long i = blockIdx.x;
-    const int64_t row = ids[i];
+    const int64_t row = ids[i] - id_base;
     for (int kx = threadIdx.x; kx < dim; kx += 256)
         out[(size_t)i * dim + kx] = (row >= 0 && row < nrows) ? cmr_load_elem<DT>(corpus, ks_total, row, kx) : 0.0f;
 }
 
-hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows, const int64_t* ids,
-                                  long long n, float* out, hipStream_t s) {
+hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows, long long id_base,
+                                  const int64_t* ids, long long n, float* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const unsigned char* c = reinterpret_cast<const unsigned char*>(corpus);
     dim3 grid((unsigned)n), block(256);
     switch (dtype) {
-        case CMR_DT_BF16: hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_BF16>, grid, block, 0, s, c, dim, ks, nrows, ids, n, out); break;
-        case CMR_DT_F16:  hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_F16>, grid, block, 0, s, c, dim, ks, nrows, ids, n, out); break;
-        case CMR_DT_F32:  hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_F32>, grid, block, 0, s, c, dim, ks, nrows, ids, n, out); break;
+        case CMR_DT_BF16: hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_BF16>, grid, block, 0, s, c, dim, ks, nrows, id_base, ids, n, out); break;
+        case CMR_DT_F16:  hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_F16>, grid, block, 0, s, c, dim, ks, nrows, id_base, ids, n, out); break;
+        case CMR_DT_F32:  hipLaunchKernelGGL(gather_rows_kernel<CMR_DT_F32>, grid, block, 0, s, c, dim, ks, nrows, id_base, ids, n, out); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -693,7 +693,7 @@ hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dp
 // whose "row" field is the candidate row id.
 template <int DT>
 __global__ __launch_bounds__(256) void rescore_kernel(const unsigned char* __restrict__ corpus, const float* __restrict__ shadow,
-                                                      int dim, int ks_total, long long nrows, const float* __restrict__ q,
+                                                      int dim, int ks_total, long long nrows, long long id_base, const float* __restrict__ q,
                                                       const int64_t* __restrict__ cand, int n_cand, int k,
                                                       int64_t* __restrict__ out_ids, float* __restrict__ out_scores) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned char* __res
     const int qi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qv = q + (size_t)qi * dim;
     for (int c = wave; c < n_cand; c += 4) {
-        const int64_t row = cand[(size_t)qi * n_cand + c];
+        const int64_t row = cand[(size_t)qi * n_cand + c] - id_base;      // candidates carry global ids
         u64 key = 0;
         if (row >= 0 && row < nrows) {
             float acc = 0.0f;
@@ -728,12 +728,12 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned char* __res
     cmr_block_select(pool, n_cand, k, res, wbest);
     for (int i = tid; i < k; i += 256) {
         const u64 key = res[i];
-        out_ids[(size_t)qi * k + i] = key ? (int64_t)cmr_key_row(key) : -1;
+        out_ids[(size_t)qi * k + i] = key ? (int64_t)cmr_key_row(key) + id_base : -1;
         out_scores[(size_t)qi * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
     }
 }
 
-hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow, int dim, int dpad, long long nrows,
+hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow, int dim, int dpad, long long nrows, long long id_base,
                               const float* q, int nq, const int64_t* cand, int n_cand, int k, int64_t* out_ids,
                               float* out_scores, hipStream_t s) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
@@ -745,7 +745,7 @@ hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rescore_kernel<DT>),                         \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
         if (e != hipSuccess) return e;                                                                                \
-        hipLaunchKernelGGL(rescore_kernel<DT>, grid, block, lds, s, c, shadow, dim, ks, nrows, q, cand, n_cand, k,    \
+        hipLaunchKernelGGL(rescore_kernel<DT>, grid, block, lds, s, c, shadow, dim, ks, nrows, id_base, q, cand, n_cand, k, \
                            out_ids, out_scores);                                                                      \
     }
     switch (dtype) {

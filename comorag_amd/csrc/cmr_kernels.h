@@ -76,11 +76,12 @@ hipError_t cmr_launch_sort_scores(const float* scores, long long n, long long id
 hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int S, int nq, int k,
                                    int64_t* out_ids, float* out_scores, hipStream_t s);
 // exact fp32 dot of queries with candidate rows, then top-k
+// (candidate and output ids are global: local row + id_base)
 hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow, int dim, int dpad,
-                              long long nrows, const float* q, int nq, const int64_t* cand, int n_cand,
+                              long long nrows, long long id_base, const float* q, int nq, const int64_t* cand, int n_cand,
                               int k, int64_t* out_ids, float* out_scores, hipStream_t s);
 // gather rows as fp32
-hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows,
+hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows, long long id_base,
                                   const int64_t* ids, long long n, float* out, hipStream_t s);
 // masked mean-pool + L2 norm
 hipError_t cmr_launch_pool(const void* hidden, int hidden_dtype, const int64_t* mask, int b, int l, int d,

@@ -16,7 +16,8 @@ ComoRAG.py / timeline_utils.py / cluster_utils.py run on it unchanged.  What dif
   reference rewrites the whole parquet file and rebuilds four dicts on every insert
   (embedding_store.py:109-120 → O(N) per insert, O(N^2) for the probe loop's incremental appends).
   Sidecar mode appends to `vdb_{ns}.rows.jsonl` (hash_id, content) + `vdb_{ns}.f32` (raw fp32
-  matrix) and updates the dicts incrementally; `export_parquet()` writes the reference-schema file
+  matrix; `vdb_{ns}.meta.json` holds the dim) and updates the dicts incrementally; a load cuts off whatever a crash
+  left behind the last complete (id line, vector) pair; `export_parquet()` writes the reference-schema file
   on demand, and an existing `vdb_{ns}.parquet` is imported on first load.
 
 Conscious deviations: `hash_id_to_text` / `text_to_hash_id` exist on an empty store too (the
@@ -76,6 +77,7 @@ class EmbeddingStore:
         self.filename = os.path.join(db_filename, f"vdb_{self.namespace}.parquet")
         self._rows_file = os.path.join(db_filename, f"vdb_{self.namespace}.rows.jsonl")
         self._mat_file = os.path.join(db_filename, f"vdb_{self.namespace}.f32")
+        self._meta_file = os.path.join(db_filename, f"vdb_{self.namespace}.meta.json")
         self._lock = threading.RLock()
         self._mat = np.empty((0, 0), dtype=np.float32)
         self._n = 0
@@ -107,29 +109,60 @@ class EmbeddingStore:
         self.text_to_hash_id = {t: h for h, t in zip(self.hash_ids, self.texts)}
 
     def _load_sidecar(self) -> bool:
+        """rows.jsonl (one [hash_id, content] per line) + .f32 (raw fp32 matrix) + .meta.json ({"dim": d}).
+        Crash safety: an append writes the matrix rows first, then the id lines, so after a crash the files can hold
+        (a) whole vectors without an id line, (b) a torn last vector, (c) a torn last id line.  The id lines that are
+        complete AND have their vector are the store; everything behind them is cut off both files."""
         import json
         if not (os.path.exists(self._rows_file) and os.path.exists(self._mat_file)):
             return False
-        with open(self._rows_file, encoding="utf-8") as f:
+        rows, good_bytes = [], 0
+        with open(self._rows_file, "rb") as f:
             for line in f:
-                if line.strip():
-                    h, t = json.loads(line)
-                    self.hash_ids.append(h); self.texts.append(t)
-        n = len(self.hash_ids)
+                if not line.endswith(b"\n"):
+                    break                      # torn last line
+                try:
+                    h, t = json.loads(line.decode("utf-8"))
+                except Exception:
+                    break
+                rows.append((h, t)); good_bytes += len(line)
+        n_float = os.path.getsize(self._mat_file) // 4
+        dim = 0
+        if os.path.exists(self._meta_file):
+            dim = int(json.load(open(self._meta_file)).get("dim", 0))
+        elif rows and n_float % len(rows) == 0:          # files of the first sidecar version carried no meta file
+            dim = n_float // len(rows)
+        if rows and dim <= 0:
+            raise IOError(f"{self._mat_file}: cannot tell the embedding dim ({n_float} floats, {len(rows)} rows, no {self._meta_file})")
+        n = min(len(rows), n_float // dim) if dim else 0
+        if n < len(rows):                      # id lines whose vectors never made it (cannot happen with this writer's order)
+            rows = rows[:n]
+            good_bytes = sum(len((json.dumps([h, t], ensure_ascii=False) + "\n").encode("utf-8")) for h, t in rows)
+        if os.path.getsize(self._rows_file) != good_bytes:
+            with open(self._rows_file, "r+b") as f:
+                f.truncate(good_bytes)
+        if os.path.getsize(self._mat_file) != n * dim * 4:
+            with open(self._mat_file, "r+b") as f:
+                f.truncate(n * dim * 4)        # orphan tail vectors are dropped, never re-interpreted
+        self.hash_ids = [h for h, _ in rows]
+        self.texts = [t for _, t in rows]
         if n:
-            flat = np.fromfile(self._mat_file, dtype=np.float32)
-            dim = len(flat) // n
-            if dim * n != len(flat):       # torn tail after a crash: keep whole rows only
-                raise IOError(f"{self._mat_file}: {len(flat)} floats is not a multiple of {n} rows")
             self._reserve(n, dim)
-            self._mat[:n] = flat.reshape(n, dim)
+            self._mat[:n] = np.fromfile(self._mat_file, dtype=np.float32, count=n * dim).reshape(n, dim)
             self._n = n
         return True
 
     def _append_sidecar(self, hash_ids, texts, rows: np.ndarray) -> None:
         import json
-        with open(self._mat_file, "ab") as f:          # matrix first: a torn write leaves extra floats, never a
-            np.ascontiguousarray(rows, dtype=np.float32).tofile(f)   # row without its vector
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if not os.path.exists(self._meta_file):
+            tmp = self._meta_file + ".tmp"
+            with open(tmp, "w") as f:
+                json.dump({"dim": int(rows.shape[1]), "dtype": "float32", "format": 2}, f)
+                f.flush(); os.fsync(f.fileno())
+            os.replace(tmp, self._meta_file)
+        with open(self._mat_file, "ab") as f:          # matrix first: a crash leaves vectors without id lines (cut off on
+            rows.tofile(f)                             # load), never an id line without its vector
             f.flush(); os.fsync(f.fileno())
         with open(self._rows_file, "a", encoding="utf-8") as f:
             for h, t in zip(hash_ids, texts):
@@ -172,6 +205,9 @@ class EmbeddingStore:
             assert len(self.hash_ids) == len(self.texts) == self._n
             logger.info(f"Loaded {len(self.hash_ids)} records from {self.filename}")
             if self.persist == "sidecar" and self._n:      # import an existing reference file once
+                for stale in (self._mat_file, self._rows_file, self._meta_file):     # e.g. vectors of a crashed first append
+                    if os.path.exists(stale):
+                        os.remove(stale)
                 self._append_sidecar(self.hash_ids, self.texts, self._mat[:self._n])
         self._rebuild_maps()
 

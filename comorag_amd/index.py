@@ -100,7 +100,8 @@ class DenseIndex:
 
     def search_dev(self, q_t, k: int, out_ids=None, out_scores=None, out_min=None, out_max=None,
                    stream: Optional[int] = None):
-        """Asynchronous search on torch CUDA tensors (enqueued on torch's current stream)."""
+        """Asynchronous search on torch CUDA tensors, enqueued on torch's current stream (also when that is the default
+        stream, handle 0): ordered after the kernels that produced `q_t`, before later readers of the outputs."""
         import torch
         assert q_t.is_cuda and q_t.dtype == torch.float32 and q_t.is_contiguous() and q_t.shape[1] == self.dim
         nq = q_t.shape[0]
@@ -130,6 +131,13 @@ class DenseIndex:
             C.c_void_p(out_min.data_ptr()) if out_min is not None else None,
             C.c_void_p(out_max.data_ptr()) if out_max is not None else None, we, C.byref(done)))
         return done
+
+    def query_status(self) -> bool:
+        """True if a `search_dev` / `search_pipelined` call since the last check saw a NaN/Inf query (those entry
+        points cannot raise without a sync; this one synchronises their streams)."""
+        f = C.c_int32(0)
+        L.check(L.lib().cmr_index_query_status(self._h, C.byref(f)))
+        return bool(f.value)
 
     def set_id_base(self, base: int) -> None:
         """Offset added to every returned row id (global id of local row 0 of a row shard)."""

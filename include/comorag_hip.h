@@ -12,10 +12,13 @@
  *    thread-local NUL-terminated message valid until the next call on that thread.
  *  - host buffers are caller-owned, C-contiguous, never retained after return.
  *  - "_dev" variants take DEVICE pointers (e.g. torch tensors' data_ptr()) and a hipStream_t
- *    passed as void* (NULL = the index's own stream); they enqueue work and return without
- *    synchronising.  Calls on one stream must not be issued concurrently from several threads.
- *    Non-finite queries are reported (CMR_ERR_NONFINITE) by the synchronous host-buffer calls only;
- *    the _dev calls cannot report them without a sync and leave the outputs unspecified.
+ *    passed as void* (NULL = the legacy default stream, which is what torch's default stream
+ *    handle is); they enqueue work on THAT stream and return without synchronising, so the work
+ *    is ordered after the caller's earlier kernels on the stream and before its later ones.
+ *    Calls on one stream must not be issued concurrently from several threads.
+ *    Non-finite queries are reported (CMR_ERR_NONFINITE) by the synchronous host-buffer calls;
+ *    the _dev and pipelined calls cannot report them without a sync: their outputs are then
+ *    unspecified and cmr_index_query_status() tells, after the fact, that it happened.
  *  - handles are opaque; destroy(NULL) is a no-op.  All functions are thread-safe: searches on
  *    one index run concurrently (shared lock), append/destroy are exclusive.
  *  - there is NO CPU fallback: without a visible gfx950 device every compute call fails with
@@ -124,6 +127,10 @@ int32_t cmr_index_set_id_base(cmr_index_t* idx, int64_t base);
  * outputs and before the next use of the same output buffers (the RCCL exchange goes there).     */
 int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream);
 
+/* Did any _dev / pipelined search since the last call see a NaN/Inf query?  Synchronises the index's pipeline streams
+ * and the streams used with the _dev API, reads and re-arms their flags.  *nonfinite = 0 / 1.                        */
+int32_t cmr_index_query_status(cmr_index_t* idx, int32_t* nonfinite);
+
 /* Helpers for callers that only hold opaque handles (e.g. a torch stream's cuda_stream):
  * make `stream` (hipStream_t) wait for `event` (hipEvent_t from *done_event), or block the host.  */
 int32_t cmr_stream_wait_event(void* stream, void* event);
@@ -148,11 +155,12 @@ int32_t cmr_index_sorted_scores(cmr_index_t* idx, const float* q_f32, int32_t nq
  * reference's rerank.py is an LLM filter with no numeric scoring (rerank.py:100-123); this is
  * the numeric stage the engine adds behind the same (indices, items, {'confidence'}) shape.
  * Uses the fp32 shadow when the index was created with CMR_FLAG_KEEP_F32, otherwise the stored
- * (rounded) rows with fp32 queries.  cand [nq, n_cand] int64 row ids (-1 = skip).              */
+ * (rounded) rows with fp32 queries.  cand [nq, n_cand] int64 row ids as the search entry points
+ * return them (i.e. including the cmr_index_set_id_base offset; -1 = skip); out_ids likewise.   */
 int32_t cmr_index_rescore(cmr_index_t* idx, const float* q_f32, int32_t nq, const int64_t* cand,
                           int32_t n_cand, int32_t k, int64_t* out_ids, float* out_scores);
 
-/* Gather rows back to the host as fp32 (dequantised), out [n, dim]. */
+/* Gather rows back to the host as fp32 (dequantised), out [n, dim]; ids as returned by search (with the id base). */
 int32_t cmr_index_get_rows(cmr_index_t* idx, const int64_t* ids, int64_t n, float* out);
 
 /* ---- multi-shard merge ------------------------------------------------------------------

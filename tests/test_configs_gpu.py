@@ -131,3 +131,105 @@ def test_config3_full_size_eight_shards_equal_one_index():
     single.close()
     for sh in shards:
         sh.close()
+
+
+def _host_oracle_topk(q32, blocks_bf16, k, extra=8):
+    """Top-(k+extra) candidates per query and block from a host fp32 GEMM over the bf16-rounded rows, then fp64 scores
+    of the pooled candidates: returns (pool ids [nq, P], exact fp64 scores of the pool [nq, P])."""
+    import torch
+    nq = q32.shape[0]
+    qt = torch.from_numpy(q32)
+    pools = []
+    base = 0
+    for xb in blocks_bf16:
+        s = qt @ xb.float().T                                    # [nq, rows] fp32 on the host cores
+        top = torch.topk(s, min(k + extra, s.shape[1]), dim=1).indices.numpy() + base
+        pools.append(top)
+        base += xb.shape[0]
+    pool = np.concatenate(pools, axis=1)
+    return pool, base
+
+
+def _exact_on(ids, q32, blocks_bf16, blk):
+    """fp64 scores of rows `ids` (global) for one query."""
+    rows = np.stack([blocks_bf16[i // blk][i % blk].float().numpy() for i in ids.tolist()])
+    return rows.astype(np.float64) @ q32.astype(np.float64)
+
+
+def test_headline_config_pipelined_vs_host_oracle():
+    """The configuration bench.py times — 10 M x 768 bf16 rows, batch 64, k = 20, cmr_index_search_pipelined (narrow
+    kernel, sampling thresholds, reserved CUs) — against an oracle at FULL size: host fp32 GEMM over the bf16-rounded
+    corpus copied back from the device, fp64 arbitration of the candidates.  Also: pipelined == synchronous, bit for bit."""
+    import torch
+    from comorag_amd.index import DenseIndex
+    rows, dim, B, k, blk = 10_000_000, 768, 64, 20, 250_000
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(20260925)
+    idx = DenseIndex(dim, "bf16", capacity_hint=rows)
+    host = []
+    for b0 in range(0, rows, blk):
+        x = torch.randn((blk, dim), generator=g, device=dev)
+        x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+        idx.append_dev(x)
+        host.append(x.to(torch.bfloat16).cpu())                  # RN-even, as the index rounds
+    q = torch.randn((B, dim), generator=g, device=dev)
+    q[:8] = torch.stack([host[5 * i][77 + i].float().to(dev) for i in range(8)]) + 0.02 * q[:8]     # planted neighbours
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+             torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)) for _ in range(2)]
+    h = None
+    for i in range(4):                                            # steady state of the pipeline: both slots used
+        o = outs[i & 1]
+        h = idx.search_pipelined(q, k, o[0], o[1], o[2], o[3])
+    idx.sync(h); torch.cuda.synchronize()
+    ids, sc, mn, mx = (t.cpu().numpy() for t in outs[1])
+    ids0, sc0 = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy()
+    assert np.array_equal(ids, ids0) and np.array_equal(sc, sc0)                  # both slots
+    qh = q.cpu().numpy()
+    sid, ssc, smn, smx = idx.search(qh, k)                                          # synchronous host API
+    assert np.array_equal(ids, sid) and np.array_equal(sc, ssc) and np.array_equal(mn, smn) and np.array_equal(mx, smx)
+    assert not idx.query_status()
+    idx.close()
+    qr = q.to(torch.bfloat16).float().cpu().numpy()                                 # queries are rounded to the index dtype
+    pool, n = _host_oracle_topk(qr, host, k)
+    assert n == rows
+    for i in range(B):
+        cand = np.union1d(pool[i], ids[i])
+        ex = _exact_on(cand, qr[i], host, blk)
+        order = np.lexsort((cand, -ex))[:k]
+        exact_full = {int(c): float(e) for c, e in zip(cand, ex)}
+        ref = cand[order]
+        if not np.array_equal(ids[i], ref):                       # only near-ties inside the fp32 accumulation bound may differ
+            for a, b in zip(ids[i], ref):
+                assert a == b or abs(exact_full[int(a)] - exact_full[int(b)]) < 4e-6, (i, a, b)
+            assert abs(min(exact_full[int(a)] for a in ids[i]) - ex[order][-1]) < 4e-6
+        np.testing.assert_allclose(sc[i], [exact_full[int(a)] for a in ids[i]], atol=4e-6)
+        assert np.all(np.diff(sc[i]) <= 0)
+    assert np.all(sc[:8, 0] > 0.9) and [int(ids[i, 0]) for i in range(8)] == [5 * i * blk + 77 + i for i in range(8)]
+    assert np.all(mx == sc[:, 0])
+
+
+def test_fp32_index_one_million_rows_vs_host_oracle():
+    """north_star's 'bit-exact top-k indices at k <= 20 for fp32' at 1 M x 768: fp32 index (v_mfma_f32_32x32x2_f32, exact
+    k-ordered fmaf chains) vs the host fp32 GEMM the reference runs (np.dot -> OpenBLAS), ids identical up to ties
+    inside the fp32 accumulation bound (arbitrated in fp64), normalised scores within 2e-6."""
+    from comorag_amd.index import DenseIndex
+    n, d, b, k = 1_000_000, 768, 32, 20
+    X = np.concatenate([orc.synthetic_corpus(250_000, d, seed=4321, block=i) for i in range(4)])
+    Q = orc.synthetic_queries(b, d, seed=78, planted=X[::50_000])
+    idx = DenseIndex(d, "f32", capacity_hint=n); idx.append(X)
+    ids, sc, mn, mx = idx.search(Q, k)
+    s32 = Q @ X.T                                                 # what ComoRAG.dense_passage_retrieval computes (:958-962)
+    ref_ids, _ = orc.topk_rule(s32, k)
+    n_diff = 0
+    for i in range(b):
+        if not np.array_equal(ids[i], ref_ids[i]):
+            n_diff += 1
+            cols = np.union1d(ids[i], ref_ids[i])
+            ex = np.full(n, -np.inf); ex[cols] = X[cols].astype(np.float64) @ Q[i].astype(np.float64)
+            orc.assert_topk_equivalent(ids[i], ref_ids[i], ex, 4e-6)
+        np.testing.assert_allclose(sc[i], s32[i][ids[i]], atol=2e-6)
+        norm = (sc[i] - mn[i]) / (mx[i] - mn[i])
+        np.testing.assert_allclose(norm, orc.min_max_normalize(s32[i])[ids[i]], atol=2e-6)
+    assert n_diff <= 2, n_diff            # identical ids is the rule; a swap needs two scores within fp32 rounding of each other
+    idx.close()

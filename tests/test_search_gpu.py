@@ -271,6 +271,99 @@ def test_nonfinite_rejected():
     idx.close()
 
 
+def test_k100_on_five_million_rows():
+    """k in 33..128 on > 4.19 M rows: the level-1 sample used to produce more candidate lists than merge_query_kernel
+    accepts (W > 4096 -> CMR_ERR_HIP).  5 M x 64 bf16 rows, k = 100 and 128, narrow and pipelined paths."""
+    import torch
+    from comorag_amd.index import DenseIndex
+    n, d = 5_000_000, 64
+    X = orc.synthetic_corpus(n, d, seed=55)
+    Q = orc.synthetic_queries(6, d, seed=56, planted=X[::500_000])
+    idx = DenseIndex(d, "bf16", capacity_hint=n); idx.append(X)
+    Xr, Qr = orc.bf16_round(X), orc.bf16_round(Q)
+    exact = Qr.astype(np.float64) @ Xr.astype(np.float64).T
+    for k in (100, 128, 33):
+        ids, sc, mn, mx = idx.search(Q, k)
+        ref_ids, _ = orc.topk_rule(exact, k)
+        for i in range(len(Q)):
+            orc.assert_topk_equivalent(ids[i], ref_ids[i], exact[i], ERR)
+    dev = torch.device("cuda", 0)
+    qt = torch.from_numpy(Q).to(dev)
+    oi = torch.empty((6, 100), dtype=torch.int64, device=dev); os_ = torch.empty((6, 100), dtype=torch.float32, device=dev)
+    idx.sync(idx.search_pipelined(qt, 100, oi, os_))
+    a_ids, a_sc = idx.search(Q, 100)[:2]
+    assert np.array_equal(oi.cpu().numpy(), a_ids) and np.array_equal(os_.cpu().numpy(), a_sc)
+    idx.close()
+
+
+def test_dev_api_on_torch_default_stream_is_ordered():
+    """search_dev / scores_dev with torch's default stream (handle 0): the queries are PRODUCED by torch kernels on that
+    stream and the outputs CONSUMED by torch kernels on it, with no device synchronisation in between — the library must
+    enqueue on the stream it was handed, not on a private one."""
+    import torch
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(200_000, 256, 16, seed=3)
+    idx = DenseIndex(256, "bf16"); idx.append(X)
+    want_ids, want_sc = idx.search(Q, 10)[:2]
+    want_full = idx.scores(Q[:2])
+    dev = torch.device("cuda", 0)
+    qh = torch.from_numpy(Q)
+    big = torch.randn((4096, 4096), device=dev)
+    for rep in range(5):
+        assert torch.cuda.current_stream(dev).cuda_stream == 0
+        junk = big @ big                                          # keeps the stream busy in front of the query producer
+        q_t = (qh.to(dev, non_blocking=True) * 2.0) / 2.0         # produced on the default stream, after `junk`
+        ids_t, sc_t = idx.search_dev(q_t, 10)
+        ids_c = ids_t.clone(); sc_c = sc_t * 1.0                  # consumers on the same stream
+        full = idx.scores_dev(q_t[:2].contiguous())
+        full_c = full + 0.0
+        del junk
+        assert np.array_equal(ids_c.cpu().numpy(), want_ids) and np.array_equal(sc_c.cpu().numpy(), want_sc)
+        assert np.array_equal(full_c.cpu().numpy(), want_full)
+    idx.close()
+
+
+def test_rescore_and_get_rows_take_global_ids():
+    """A row shard with an id base: search returns global ids; rescore / get_rows must accept exactly those."""
+    from comorag_amd.index import DenseIndex
+    from comorag_amd.rerank import search_then_rescore
+    X, Q = _mk(5000, 128, 3, seed=31)
+    a = DenseIndex(128, "bf16", keep_f32=True); a.append(X)
+    b = DenseIndex(128, "bf16", keep_f32=True); b.append(X); b.set_id_base(1_000_000)
+    ia, sa = a.search(Q, 50)[:2]
+    ib, sb = b.search(Q, 50)[:2]
+    assert np.array_equal(ib, ia + 1_000_000) and np.array_equal(sa, sb)
+    ra, rsa = a.rescore(Q, ia, 10)
+    rb, rsb = b.rescore(Q, ib, 10)
+    assert np.array_equal(rb, ra + 1_000_000) and np.array_equal(rsa, rsb) and np.all(ra >= 0)
+    assert np.array_equal(b.get_rows(ib[0, :5]), a.get_rows(ia[0, :5]))
+    ja, _ = search_then_rescore(a, Q, 50, 10)
+    jb, _ = search_then_rescore(b, Q, 50, 10)
+    assert np.array_equal(jb, ja + 1_000_000)
+    a.close(); b.close()
+
+
+def test_query_status_reports_nonfinite_dev_queries():
+    import torch
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(3000, 64, 4, seed=41)
+    idx = DenseIndex(64, "bf16"); idx.append(X)
+    dev = torch.device("cuda", 0)
+    q = torch.from_numpy(Q).to(dev)
+    idx.search_dev(q, 5); torch.cuda.synchronize()
+    assert idx.query_status() is False
+    qb = q.clone(); qb[1, 3] = float("nan")
+    idx.search_dev(qb, 5); torch.cuda.synchronize()
+    assert idx.query_status() is True and idx.query_status() is False        # reported once, then re-armed
+    oi = torch.empty((4, 5), dtype=torch.int64, device=dev); os_ = torch.empty((4, 5), dtype=torch.float32, device=dev)
+    qb[1, 3] = float("inf")
+    idx.sync(idx.search_pipelined(qb, 5, oi, os_))
+    assert idx.query_status() is True
+    idx.sync(idx.search_pipelined(q, 5, oi, os_))
+    assert idx.query_status() is False
+    idx.close()
+
+
 def test_golden_dpr_fp32(golden_dir):
     """fp32 index vs the REFERENCE's dense_passage_retrieval / get_fact_scores outputs."""
     from comorag_amd.index import DenseIndex

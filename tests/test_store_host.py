@@ -147,6 +147,42 @@ def test_sidecar_persistence_is_append_only_and_equivalent(tmp_path, fake_embedd
     assert c2.hash_ids == a.hash_ids + [compute_mdhash_id("brand new", prefix="chunk-")]
 
 
+def test_sidecar_load_survives_a_crash_between_the_two_appends(tmp_path):
+    """An append writes vectors first, id lines second.  A crash in between leaves whole orphan vectors (or a torn one,
+    or a torn id line); the next load must come up with exactly the complete (id, vector) pairs — not raise forever, and
+    never re-interpret the floats with a wrong dim (2 rows of dim 8 + 2 orphan rows used to load as 2 rows of dim 16)."""
+    from tests.conftest import FakeEmbedder
+    d = str(tmp_path / "s")
+    a = EmbeddingStore(FakeEmbedder(8), d, 8, "chunk", persist="sidecar")
+    a.insert_strings(["one", "two"])
+    want_ids, want = list(a.hash_ids), np.array(a.get_embeddings(a.get_all_ids()))
+    orphan = np.arange(16, dtype=np.float32)
+    for tail_f32, tail_rows in ((orphan.tobytes(), b""),                                  # two whole orphan vectors
+                                (orphan.tobytes()[:20], b""),                             # a torn vector
+                                (orphan.tobytes(), b'["chunk-deadbeef", "thr')):          # vectors + a torn id line
+        with open(a._mat_file, "ab") as f:
+            f.write(tail_f32)
+        with open(a._rows_file, "ab") as f:
+            f.write(tail_rows)
+        b = EmbeddingStore(FakeEmbedder(8), d, 8, "chunk", persist="sidecar")
+        assert b.hash_ids == want_ids and b._mat.shape[1] == 8
+        np.testing.assert_array_equal(b.get_embeddings(b.get_all_ids()), want)
+        assert os.path.getsize(b._mat_file) == 2 * 8 * 4                  # the tail is gone: later appends line up again
+    b.insert_strings(["three"])
+    c = EmbeddingStore(FakeEmbedder(8), d, 8, "chunk", persist="sidecar")
+    assert c.hash_ids == want_ids + [compute_mdhash_id("three", prefix="chunk-")] and len(c.embeddings) == 3
+    np.testing.assert_array_equal(c.get_embedding(c.hash_ids[2]), FakeEmbedder(8)._vec("three"))
+    # import path: a parquet file next to stale sidecar vectors (crashed first append, no id file): the parquet rows win
+    p = str(tmp_path / "p")
+    EmbeddingStore(FakeEmbedder(8), p, 8, "chunk").insert_strings(["one", "two"])
+    with open(os.path.join(p, "vdb_chunk.f32"), "wb") as f:
+        f.write(orphan.tobytes())
+    e = EmbeddingStore(FakeEmbedder(8), p, 8, "chunk", persist="sidecar")
+    assert e.hash_ids == want_ids and os.path.getsize(e._mat_file) == 2 * 8 * 4
+    e2 = EmbeddingStore(FakeEmbedder(8), p, 8, "chunk", persist="sidecar")
+    np.testing.assert_array_equal(e2.get_embeddings(e2.get_all_ids()), want)
+
+
 def test_tokenize_batch_equals_the_reference_tokenizer_call():
     """comorag_amd.embedding_model.bge.tokenize_batch must hand the encoder exactly what
     BGEEmbedding.py:112-117 does (`tokenizer(prompts, padding=True, truncation=True, max_length=...,
