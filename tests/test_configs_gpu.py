@@ -205,7 +205,7 @@ def test_headline_config_pipelined_vs_host_oracle():
             assert abs(min(exact_full[int(a)] for a in ids[i]) - ex[order][-1]) < 4e-6
         np.testing.assert_allclose(sc[i], [exact_full[int(a)] for a in ids[i]], atol=4e-6)
         assert np.all(np.diff(sc[i]) <= 0)
-    assert np.all(sc[:8, 0] > 0.9) and [int(ids[i, 0]) for i in range(8)] == [5 * i * blk + 77 + i for i in range(8)]
+    assert np.all(sc[:8, 0] > 0.8) and [int(ids[i, 0]) for i in range(8)] == [5 * i * blk + 77 + i for i in range(8)]
     assert np.all(mx == sc[:, 0])
 
 
