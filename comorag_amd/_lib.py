@@ -60,6 +60,12 @@ SIGNATURES = {
     "cmr_index_get_rows": (_i32, [_p, _p, _i64, _p]),
     "cmr_merge_topk": (_i32, [_p, _p, _i32, _i32, _i32, _p, _p]),
     "cmr_merge_topk_dev": (_i32, [_i32, _p, _p, _i32, _i32, _i32, _p, _p, _p]),
+    "cmr_pack_candidates_dev": (_i32, [_p, _p, _i64, _p, _p]),
+    "cmr_merge_keys_dev": (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),
+    "cmr_comm_unique_id": (_i32, [_p]),
+    "cmr_comm_create": (_i32, [_i32, _i32, _p, _i32, _P(_p)]),
+    "cmr_comm_destroy": (_i32, [_p]),
+    "cmr_comm_allgather_merge": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p]),
     "cmr_pool_l2norm": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_profile_enable": (_i32, [_p, _i32]),
     "cmr_profile_collect": (_i32, [_p, _P(_i64), _P(_f64), _P(_f64)]),

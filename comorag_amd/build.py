@@ -29,7 +29,7 @@ STAMP = os.path.join(LIBDIR, "build_stamp.json")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip"]
+SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip"]
 HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 
 _KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
@@ -218,14 +218,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     "        }\n"
                     "    return any;\n"
                     "}\n")
-        for src in ("aux_kernels.hip", "api.hip"):
+        for src in ("aux_kernels.hip", "api.hip", "comm.hip"):
             o = os.path.join(tmp, src.replace(".hip", ".o"))
             _run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", o], cwd=tmp)
             objs.append(o)
         o = os.path.join(tmp, "ring_audit.o")
         _run([HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(tmp, "ring_audit.cpp"), "-o", o], cwd=tmp)
         objs.append(o)
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs])
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     n_ok = sum(audit.values())
     info = {"hash": want, "arch": ARCH, "wide_variants_audited": len(wide), "asm_ring_variants": len(audit), "asm_ring_safe": n_ok,
             "unsafe": [list(k) for k, v in sorted(audit.items()) if not v]}

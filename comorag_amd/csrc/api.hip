@@ -27,10 +27,11 @@ bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring);  // ring_audit.cp
 static const long long kMaxMergeLists = 4096;                    // merge_query_kernel: W <= 16 * MERGE_THREADS
 
 namespace {
-
 thread_local std::string g_err;
+}
 
-int fail(int code, const char* fmt, ...) {
+// sets the thread's error message; also used by comm.hip
+int cmr_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -39,6 +40,9 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+#define fail cmr_fail
+
+namespace {
 
 #define HIP_TRY(expr)                                                                             \
     do {                                                                                          \

@@ -1,12 +1,15 @@
 """Row-sharded index across the GPUs of one node: one process per GPU (torch.distributed,
-backend "nccl" = RCCL over xGMI), contiguous row blocks per rank, one all-gather of the per-shard
-[B,k] (score, global id) candidates per query batch, then the final merge with the exported tie
-rule — so the result equals a single-shard search by construction.  The reference
-has no distributed path; nothing here mirrors reference code.
+backend "nccl" = RCCL over xGMI), contiguous row blocks per rank, ONE all-gather of the per-shard
+[B,k] candidates per query batch — each candidate packed into a single u64 (order-preserving score
+code | ~global row: unsigned order is the exported order) — then the final merge, so the result
+equals a single-shard search by construction.  The reference has no distributed
+path; nothing here mirrors reference code.
 
-The candidate exchange is B*k*12 bytes per rank (15 KiB at B=64,k=20): latency-bound, so the
-all-gather + merge of batch i run on a side stream while the scan of batch i+1 runs on the main
-stream (`search_pipelined`).
+The candidate exchange is B*k*8 bytes per rank (10 KiB at B=64,k=20): latency-bound, so the
+all-gather + merge of batch i run on the index pipeline's post stream while the scan of batch i+1
+runs on its scan stream (`search_pipelined`).  Two bindings of the same exchange:
+  exchange="torch"  torch.distributed.all_gather_into_tensor between cmr_pack_candidates_dev and cmr_merge_keys_dev
+  exchange="cabi"   cmr_comm_allgather_merge: RCCL called by the library itself (no torch in the data path)
 """
 from __future__ import annotations
 
@@ -26,11 +29,18 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
 
 class ShardedIndex:
     def __init__(self, dim: int, dtype: str = "bf16", device: int = 0, rank: int = 0, world: int = 1,
-                 group=None, base: int = 0, capacity_hint: int = 0, index=None, force_exchange: bool = False):
+                 group=None, base: int = 0, capacity_hint: int = 0, index=None, force_exchange: bool = False,
+                 exchange: str = "torch", timing: bool = False):
         self.dim, self.dtype, self.device = dim, dtype, device
         self.rank, self.world, self.group = rank, world, group
         self.base = int(base)          # global id of local row 0
         self.exchange = world > 1 or force_exchange   # force_exchange: run the RCCL path on a 1-rank group (tests)
+        if exchange not in ("torch", "cabi"):
+            raise ValueError("exchange must be 'torch' or 'cabi'")
+        self.exchange_kind = exchange
+        self.timing = timing           # record exchange / merge times of every pipelined batch (bench.py)
+        self.times = []                # (event before exchange, after all-gather, after merge) per batch
+        self._comm = None
         if index is None:
             from .index import DenseIndex
             index = DenseIndex(dim, dtype, device=device, capacity_hint=capacity_hint)
@@ -64,14 +74,12 @@ class ShardedIndex:
         if self.world == 1:
             return merge_topk(pid[None], psc[None])
         dev = torch.device("cuda", self.device) if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
-        t_id = torch.from_numpy(pid).to(dev)
-        t_sc = torch.from_numpy(psc).to(dev)
+        t_key = torch.from_numpy(pack_candidates(pid, psc).view(np.int64)).to(dev)
         # concatenated layout [world*nq, k] (accepted by both gloo and RCCL), viewed as [world, nq, k]
-        g_id = torch.empty((self.world * nq, k), dtype=torch.int64, device=dev)
-        g_sc = torch.empty((self.world * nq, k), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(g_id, t_id, group=self.group)
-        dist.all_gather_into_tensor(g_sc, t_sc, group=self.group)
-        return merge_topk(g_id.cpu().numpy().reshape(self.world, nq, k), g_sc.cpu().numpy().reshape(self.world, nq, k))
+        g_key = torch.empty((self.world * nq, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(g_key, t_key, group=self.group)                 # the one collective of the batch
+        g_ids, g_sc = unpack_candidates(g_key.cpu().numpy().view(np.uint64).reshape(self.world, nq, k))
+        return merge_topk(g_ids, g_sc)
 
     # ---------------------------------------------------------------- device path
     def _buffers(self, slot: int, nq: int, k: int, dev):
@@ -81,8 +89,8 @@ class ShardedIndex:
             self._bufs[key] = dict(
                 ids=torch.empty((nq, k), dtype=torch.int64, device=dev),
                 sc=torch.empty((nq, k), dtype=torch.float32, device=dev),
-                g_ids=torch.empty((self.world * nq, k), dtype=torch.int64, device=dev),    # == [world, nq, k]
-                g_sc=torch.empty((self.world * nq, k), dtype=torch.float32, device=dev),
+                keys=torch.empty((nq, k), dtype=torch.int64, device=dev),                   # packed candidates (u64 bit patterns)
+                g_keys=torch.empty((self.world * nq, k), dtype=torch.int64, device=dev),    # == [world, nq, k]
                 o_ids=None, o_sc=None, done=None)
             b = self._bufs[key]
             if self.exchange:
@@ -115,17 +123,87 @@ class ShardedIndex:
             if self._post is None:
                 self._post = self.local.pipeline_stream(2)
             with torch.cuda.stream(self._post):
-                dist.all_gather_into_tensor(b["g_ids"], b["ids"], group=self.group)
-                dist.all_gather_into_tensor(b["g_sc"], b["sc"], group=self.group)
-                L.check(L.lib().cmr_merge_topk_dev(
-                    self.device, C.c_void_p(b["g_ids"].data_ptr()), C.c_void_p(b["g_sc"].data_ptr()), self.world, nq, k,
-                    C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), C.c_void_p(self._post.cuda_stream)))
+                ps = C.c_void_p(self._post.cuda_stream)
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.timing else None
+                if evs: evs[0].record(self._post)
+                if self.exchange_kind == "cabi":
+                    L.check(L.lib().cmr_comm_allgather_merge(
+                        self.comm(), C.c_void_p(b["ids"].data_ptr()), C.c_void_p(b["sc"].data_ptr()), nq, k,
+                        C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), ps))
+                    if evs: evs[1].record(self._post)
+                else:
+                    L.check(L.lib().cmr_pack_candidates_dev(C.c_void_p(b["ids"].data_ptr()), C.c_void_p(b["sc"].data_ptr()), nq * k,
+                                                            C.c_void_p(b["keys"].data_ptr()), ps))
+                    dist.all_gather_into_tensor(b["g_keys"], b["keys"], group=self.group)     # the one collective of the batch
+                    if evs: evs[1].record(self._post)
+                    L.check(L.lib().cmr_merge_keys_dev(C.c_void_p(b["g_keys"].data_ptr()), self.world, nq, k,
+                                                       C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), ps))
+                if evs:
+                    evs[2].record(self._post)
+                    self.times.append(evs)
                 ev = torch.cuda.Event()
                 ev.record(self._post)
             b["done"] = ev
         else:
             b["done"] = _Done(self.local, handle)
         return b
+
+
+    # ---------------------------------------------------------------- C-ABI communicator
+    def comm(self):
+        """The library's own RCCL communicator (cmr_comm_*), created on first use: rank 0 draws the unique id, the
+        group's object broadcast ships its 128 bytes (any channel would do), every rank joins."""
+        if self._comm is None:
+            import ctypes as C
+            import torch.distributed as dist
+            uid = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                L.check(L.lib().cmr_comm_unique_id(uid))
+            if self.world > 1:
+                box = [bytes(uid)]
+                dist.broadcast_object_list(box, src=0, group=self.group)
+                uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            h = C.c_void_p()
+            L.check(L.lib().cmr_comm_create(self.world, self.rank, uid, self.device, C.byref(h)))
+            self._comm = h
+        return self._comm
+
+    def close(self):
+        if self._comm is not None:
+            L.lib().cmr_comm_destroy(self._comm)
+            self._comm = None
+        self.local.close()
+
+    def exchange_times_ms(self):
+        """[(all-gather ms, merge ms)] of the batches recorded with timing=True (for the 'cabi' binding the first number
+        is the whole pack + all-gather + merge call).  Synchronises the recorded events."""
+        out = []
+        for e0, e1, e2 in self.times:
+            e2.synchronize()
+            out.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        self.times = []
+        return out
+
+
+def pack_candidates(ids: np.ndarray, scores: np.ndarray) -> np.ndarray:
+    """(global row id, raw score) -> u64 keys whose unsigned order is the exported order (score desc, id asc); id < 0 -> 0.
+    numpy twin of cmr_pack_candidates_dev (host / gloo path)."""
+    ids = np.asarray(ids, np.int64)
+    if ids.size and ids.max(initial=-1) >= 0xFFFFFFFF:
+        raise ValueError("packed candidate exchange needs global row ids < 2^32 - 1")
+    u = (np.asarray(scores, np.float32) + np.float32(0.0)).view(np.uint32)
+    code = np.where(u & 0x80000000, ~u, u | 0x80000000).astype(np.uint64)
+    key = (code << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - ids.clip(min=0).astype(np.uint64))
+    return np.where(ids < 0, np.uint64(0), key)
+
+
+def unpack_candidates(keys: np.ndarray):
+    keys = np.asarray(keys, np.uint64)
+    code = (keys >> np.uint64(32)).astype(np.uint32)
+    u = np.where(code & 0x80000000, code & 0x7FFFFFFF, ~code).astype(np.uint32)
+    ids = np.where(keys == 0, np.int64(-1), (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int64))
+    sc = np.where(keys == 0, np.float32(-np.inf), u.view(np.float32))
+    return ids, sc.astype(np.float32)
 
 
 class _Done:

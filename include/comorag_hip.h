@@ -173,6 +173,30 @@ int32_t cmr_merge_topk_dev(int32_t device_id, const int64_t* ids_dev, const floa
                            int32_t n_shards, int32_t nq, int32_t k, int64_t* out_ids_dev,
                            float* out_scores_dev, void* stream);
 
+/* ---- row-shard exchange ------------------------------------------------------------------
+ * One process per GPU, each with a row shard (cmr_index_set_id_base makes its searches return global ids).  Per query
+ * batch every rank packs its [nq, k] candidates into ONE u64 each — the order-preserving score code in the high word,
+ * ~(global row) in the low word, so unsigned order == the exported order; global rows must be < 2^32 - 1 — all-gathers
+ * them with a single collective (nq*k*8 bytes per rank; latency-bound over xGMI) and merges world*k keys per query.
+ * The result equals a single-shard search by construction.  (No reference counterpart)
+ *
+ * cmr_pack_candidates_dev / cmr_merge_keys_dev are the two kernels on their own, for hosts that bring their own
+ * collective (comorag_amd/sharded.py runs torch.distributed's all_gather_into_tensor between them).
+ * cmr_comm_* wrap RCCL itself (bound with dlopen at first use — the RCCL already in the process when there is one):
+ * rank 0 calls cmr_comm_unique_id and ships the 128 bytes to the other ranks by any channel, every rank calls
+ * cmr_comm_create (collective), then cmr_comm_allgather_merge per batch on a stream of its choice — the index
+ * pipeline's post stream (cmr_index_pipeline_stream(idx, 2)) orders it after the batch's outputs.                     */
+#define CMR_COMM_ID_BYTES 128
+typedef struct cmr_comm cmr_comm_t;
+int32_t cmr_pack_candidates_dev(const int64_t* ids_dev, const float* scores_dev, int64_t n, uint64_t* keys_dev, void* stream);
+int32_t cmr_merge_keys_dev(const uint64_t* keys_dev /*[n_shards][nq][k]*/, int32_t n_shards, int32_t nq, int32_t k,
+                           int64_t* out_ids_dev, float* out_scores_dev, void* stream);
+int32_t cmr_comm_unique_id(uint8_t* out_id128);
+int32_t cmr_comm_create(int32_t world, int32_t rank, const uint8_t* id128, int32_t device_id, cmr_comm_t** out);
+int32_t cmr_comm_destroy(cmr_comm_t* comm);
+int32_t cmr_comm_allgather_merge(cmr_comm_t* comm, const int64_t* ids_dev, const float* scores_dev, int32_t nq, int32_t k,
+                                 int64_t* out_ids_dev, float* out_scores_dev, void* stream);
+
 /* ---- encoder tail -----------------------------------------------------------------------
  * Fused masked mean-pool + L2-normalise of the encoder's last hidden state; replaces
  * mean_pooling (embedding_model/BGEEmbedding.py:15-28) + F.normalize (:126-127, eps 1e-12).

@@ -274,6 +274,18 @@ def test_logical_shards_equal_single_index(S):
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert np.array_equal(oi.cpu().numpy(), wi) and np.array_equal(os_.cpu().numpy(), ws)
+    # the packed exchange format: one u64 per candidate (what the single all-gather ships), then the key merge
+    from comorag_amd.sharded import pack_candidates, unpack_candidates
+    keys = torch.empty((S, 9, 20), dtype=torch.int64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.check(L.lib().cmr_pack_candidates_dev(C.c_void_p(gi.data_ptr()), C.c_void_p(gs.data_ptr()), S * 9 * 20, C.c_void_p(keys.data_ptr()), st))
+    L.check(L.lib().cmr_merge_keys_dev(C.c_void_p(keys.data_ptr()), S, 9, 20, C.c_void_p(oi.data_ptr()), C.c_void_p(os_.data_ptr()), st))
+    torch.cuda.synchronize()
+    assert np.array_equal(oi.cpu().numpy(), wi) and np.array_equal(os_.cpu().numpy(), ws)
+    hk = keys.cpu().numpy().view(np.uint64)
+    assert np.array_equal(hk, pack_candidates(np.stack(ids), np.stack(scs)))          # numpy twin (gloo / host path) packs identically
+    ui, us = unpack_candidates(hk)
+    assert np.array_equal(ui, np.stack(ids)) and np.array_equal(us, np.stack(scs))
     one.close()
 
 
@@ -323,9 +335,9 @@ def test_pipelined_search_single_rank():
 
 
 def test_rccl_exchange_path_one_rank(tmp_path):
-    """The N>1 code path (ExternalStream on the pipeline's post stream → RCCL all_gather_into_tensor →
-    cmr_merge_topk_dev) run mechanically on a 1-rank `nccl` group in a subprocess (a single-GPU box
-    cannot host two RCCL ranks).  Numerics of multi-shard merging are covered by the logical-shard
+    """The N>1 code path (ExternalStream on the pipeline's post stream → cmr_pack_candidates_dev → ONE RCCL
+    all_gather_into_tensor → cmr_merge_keys_dev; and the library's own cmr_comm_allgather_merge) run mechanically
+    on a 1-rank group in a subprocess (a single-GPU box cannot host two RCCL ranks).  Numerics of multi-shard merging are covered by the logical-shard
     and gloo tests."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""
@@ -350,6 +362,15 @@ def test_rccl_exchange_path_one_rank(tmp_path):
         assert np.array_equal(b["o_ids"].cpu().numpy(), wi + 500) and np.array_equal(b["o_sc"].cpu().numpy(), ws)
         hi, hs = sh.search(Q, 20)
         assert np.array_equal(hi, wi + 500)
+        # the same exchange through the library's own RCCL communicator (cmr_comm_*: no torch collective in the path)
+        sh2 = ShardedIndex(128, "bf16", rank=0, world=1, base=500, force_exchange=True, exchange="cabi", timing=True, index=sh.local)
+        for i in range(6):
+            b2 = sh2.search_pipelined(q, 20, i & 1)
+        b2["done"].synchronize()
+        assert np.array_equal(b2["o_ids"].cpu().numpy(), wi + 500) and np.array_equal(b2["o_sc"].cpu().numpy(), ws)
+        t = sh2.exchange_times_ms()
+        assert len(t) == 6 and all(a >= 0 and m >= 0 for a, m in t)
+        sh2.close()
         dist.destroy_process_group()
         print("EXCHANGE_OK")
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
