@@ -3,16 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-Step      = one batch of B queries against the whole (row-sharded) corpus: query packing, the fused
-            MFMA scan + top-k kernel, candidate merge; for N>1 also the RCCL all-gather of the
-            per-shard [B,k] candidates and the final merge.  Inputs (corpus, queries) are resident
-            in HBM before the timed region.
-Workload  = north_star's quoted target: 10 M x 768 bf16 rows, B=64, k=20, total corpus FIXED as N
-            grows (strong scaling; rank r holds rows [r*10M/N, (r+1)*10M/N)).  BASELINE config 2
-            (1 M rows) is measured too at N=1 and reported under "extra".
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event time of
-the scan kernel, algorithmic bytes) and `cpu_baseline` (oracle = numpy restatement of the
-reference's dense_passage_retrieval, on this box's host cores, bounded sample).
+Step      = one batch of B queries against the whole (row-sharded) corpus: query packing, sampling passes, the fused
+            MFMA scan + top-k kernel, candidate merge; for N>1 also the ONE RCCL all-gather of the packed per-shard
+            [B,k] candidates and the final merge.  Inputs (corpus, queries) are resident in HBM before the timed region.
+Workload  = north_star's quoted target: 10 M x 768 bf16 rows, B=64, k=20, total corpus FIXED as N grows (strong
+            scaling; rank r holds rows [r*10M/N, (r+1)*10M/N)).  BASELINE config 3 as written (the same corpus, batch
+            256) is timed too at every N ("config3_batch256"); BASELINE config 2 (1 M rows) and the other extras at N=1.
+After the timed loop the LAST pipelined batch is compared with a synchronous search of the same batch (must be
+bit-identical), and recall@k against the fp32 CPU ranking is computed from THOSE ids.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event time of the scan kernel on
+its own stream, algorithmic bytes) and `cpu_baseline` (the oracle's restatement of the reference's CPU code on this
+box's host cores, bounded samples).
 """
 from __future__ import annotations
 
@@ -29,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 peak (spec)
 
 
 def parse():
@@ -41,9 +43,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "cabi"], help="N>1: torch.distributed collective or the library's own RCCL call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
@@ -60,14 +63,18 @@ def gen_rows_dev(torch, lo, hi, dim, device, block=250_000):
         yield x[s - b * block:e - b * block].contiguous()
 
 
-def build_shard(torch, args, rows, rank, world, device, keep_host=None):
+def build_shard(torch, args, rows, rank, world, device, host=None, timing=False):
+    """host: a preallocated fp32 array [hi - lo, dim] that receives the shard's rows (for the CPU legs)."""
     from comorag_amd.sharded import ShardedIndex, shard_bounds
     lo, hi = shard_bounds(rows, world, rank)
-    sh = ShardedIndex(args.dim, args.dtype, device=device.index, rank=rank, world=world, base=lo, capacity_hint=hi - lo)
+    sh = ShardedIndex(args.dim, args.dtype, device=device.index, rank=rank, world=world, base=lo, capacity_hint=hi - lo,
+                      exchange=args.exchange, timing=timing)
+    at = 0
     for blk in gen_rows_dev(torch, lo, hi, args.dim, device):
         sh.local.append_dev(blk)
-        if keep_host is not None:
-            keep_host.append(blk.cpu().numpy())
+        if host is not None:
+            host[at:at + len(blk)] = blk.cpu().numpy()
+        at += len(blk)
     torch.cuda.synchronize(device)
     return sh
 
@@ -76,6 +83,7 @@ def run_steps(torch, dist, sh, q, k, steps, warmup, world, device):
     for i in range(warmup):
         sh.search_pipelined(q, k, i & 1)["done"].synchronize()
     torch.cuda.synchronize(device)
+    sh.times = []
     sh.local.profile(True)
     if world > 1:
         dist.barrier()
@@ -95,19 +103,47 @@ def run_steps(torch, dist, sh, q, k, steps, warmup, world, device):
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    return dt, prof
+    ex = sh.exchange_times_ms() if sh.timing else []
+    prof["exchange_ms"] = float(np.mean([a for a, _ in ex])) if ex else 0.0
+    prof["merge_ms"] = float(np.mean([m for _, m in ex])) if ex else 0.0
+    return dt, prof, last
 
 
-def cpu_baseline(args, seconds, X, Q, gpu_ids):
-    """Oracle (numpy restatement of ComoRAG.dense_passage_retrieval, ComoRAG.py:950-967: np.dot +
-    min-max + full argsort, fp32, OpenBLAS on all cores) on the first 1 M rows of the SAME corpus the
-    GPU scanned (copied back from HBM), plus recall@20 of the bf16 GPU result vs the fp32 CPU ranking."""
-    from oracle import retrieval_np as orc
+def verify_last_batch(sh, last, qh, k):
+    """The outputs of the LAST timed pipelined batch vs a synchronous search of the same batch (host-buffer API; for N>1
+    the host path with its own all-gather + host merge): must be bit-identical."""
+    ids = last["o_ids"].cpu().numpy().copy()
+    sc = last["o_sc"].cpu().numpy().copy()
+    sid, ssc = sh.search(qh, k)
+    ok = bool(np.array_equal(ids, sid) and np.array_equal(sc, ssc))
+    return ids, sc, ok
+
+
+def thread_info():
+    info = {"os_cpu_count": os.cpu_count()}
     try:
         from threadpoolctl import threadpool_info
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        info["threadpool_info"] = [{k: p.get(k) for k in ("user_api", "internal_api", "num_threads", "version")} for p in threadpool_info()]
+        info["blas_threads"] = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
-        blas_threads = os.cpu_count() or 1
+        info["blas_threads"] = os.cpu_count() or 1
+    try:
+        import torch
+        info["torch_num_threads"] = torch.get_num_threads()
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(args, seconds, X, Q, gpu_ids, full_size):
+    """The oracle (= numpy / torch-CPU restatement of the reference's code; the reference tree itself is not on the GPU
+    box, hence kind "port") on this box's host cores, over the SAME rows the GPU scanned (copied back from HBM):
+      (i)   single-query ComoRAG.dense_passage_retrieval (ComoRAG.py:950-967: np.dot + min-max + full argsort, fp32)
+      (ii)  batched retrieve_knn forced onto the CPU (utils/embed_utils.py:8-97: torch.mm + torch.topk), B=64, k=20, 1 M keys
+      (iii) batch_encode chunks/s on the CPU (BGEEmbedding.py:131-185 on the same random-init BERT-base)
+    plus recall@k of the bf16 GPU ids of the timed configuration vs the fp32 CPU ranking of the same rows."""
+    from oracle import retrieval_np as orc
+    ti = thread_info()
     n = len(X)
     orc.dense_passage_retrieval(X, Q[:1])  # warm
     t0 = time.perf_counter()
@@ -118,13 +154,57 @@ def cpu_baseline(args, seconds, X, Q, gpu_ids):
     dt = time.perf_counter() - t0
     qps_sample = done / dt
     scale = n / args.rows
-    ref_ids, _ = orc.topk_rule(Q @ X.T, args.k)
+    # recall: fp32 ranking of the same rows, chunked so the [B, n] score block stays small
+    import torch
+    qt = torch.from_numpy(Q)
+    best_s = torch.full((len(Q), args.k), -np.inf); best_i = torch.zeros((len(Q), args.k), dtype=torch.int64)
+    step = 1_000_000
+    for lo in range(0, n, step):
+        s = qt @ torch.from_numpy(X[lo:lo + step]).T
+        ts, ti_ = torch.topk(s, min(args.k, s.shape[1]), dim=1)
+        cs, ci = torch.cat([best_s, ts], 1), torch.cat([best_i, ti_ + lo], 1)
+        o = torch.topk(cs, args.k, dim=1).indices
+        best_s, best_i = torch.gather(cs, 1, o), torch.gather(ci, 1, o)
+    ref_ids = best_i.numpy()
     recall = float(np.mean([len(set(gpu_ids[i].tolist()) & set(ref_ids[i].tolist())) / args.k for i in range(len(Q))]))
-    return {"value": qps_sample * scale, "unit": "queries/s", "cores": int(blas_threads), "kind": "port",
-            "sample": f"{done} single-query dense_passage_retrieval calls (np.dot+min-max+argsort, fp32) over the first "
-                      f"{n} rows of the bench corpus in {dt:.1f}s = {qps_sample:.2f} q/s; linearly scaled x{scale:g} to {args.rows} rows",
-            "host_cpus": os.cpu_count(), "recall_at_k_vs_cpu_fp32": recall,
-            "recall_note": f"top-{args.k} ids of the {args.dtype} HIP index vs fp32 numpy ranking, {len(Q)} queries, {n} rows"}
+    out = {"value": qps_sample * scale, "unit": "queries/s", "cores": int(ti.get("blas_threads", 1)), "kind": "port",
+           "kind_note": "oracle/retrieval_np.py, the line-by-line numpy restatement of the reference functions (pinned to reference "
+                        "outputs in tests/); the reference tree itself does not exist on the GPU box",
+           "sample": f"{done} single-query dense_passage_retrieval calls (np.dot + min-max + full argsort, fp32) over "
+                     f"{'ALL' if full_size else 'the first'} {n} rows of the bench corpus in {dt:.1f}s = {qps_sample:.3f} q/s"
+                     + ("" if full_size else f"; linearly scaled x{scale:g} to {args.rows} rows (host RAM too small for the fp32 copy)"),
+           "host_cpus": os.cpu_count(), "threads": ti,
+           "recall_at_k_vs_cpu_fp32": recall,
+           "recall_note": f"top-{args.k} ids of the {args.dtype} HIP index from the LAST TIMED PIPELINED batch of the headline configuration "
+                          f"vs the fp32 CPU ranking (torch.mm + topk), {len(Q)} queries, {n} rows"}
+    # (ii) batched CPU comparator
+    try:
+        nk = min(n, 1_000_000)
+        orc.retrieve_knn_torch_cpu(Q[:8], X[:100_000], k=args.k)
+        t0 = time.perf_counter(); reps = 0
+        while reps < 3 and time.perf_counter() - t0 < max(4.0, seconds / 3):
+            orc.retrieve_knn_torch_cpu(Q, X[:nk], k=args.k); reps += 1
+        dtb = (time.perf_counter() - t0) / max(reps, 1)
+        out["batched_retrieve_knn"] = {"value": len(Q) / dtb, "unit": "queries/s", "batch": len(Q), "k": args.k, "keys": nk, "ms_per_batch": dtb * 1e3,
+                                       "what": "utils/embed_utils.py:8-97 forced onto the CPU (fp32 normalise, torch.mm + torch.topk per 10000-key block, merge)"}
+    except Exception as e:
+        out["batched_retrieve_knn"] = {"error": repr(e)[:300]}
+    # (iii) CPU encode
+    try:
+        from oracle import encode_torch as enc
+        from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+        tok, words = synthetic_wordpiece_tokenizer()
+        model = random_bert("base", vocab_size=len(tok))
+        chunks = synthetic_chunks(words, 8)
+        enc.encode(model, tok, chunks[:1], instruction=enc.BGE_PREFIX)
+        t0 = time.perf_counter()
+        enc.batch_encode(model, tok, chunks, batch_size=8) if hasattr(enc, "batch_encode") else enc.encode(model, tok, chunks, instruction=enc.BGE_PREFIX)
+        dte = time.perf_counter() - t0
+        out["batch_encode"] = {"value": len(chunks) / dte, "unit": "chunks/s", "chunks": len(chunks), "model": "BERT-base shape, random init, fp32, CPU",
+                               "what": "embedding_model/BGEEmbedding.py:92-185 restated (tokenise + forward + mean-pool + L2-normalise), ~480-token chunks"}
+    except Exception as e:
+        out["batch_encode"] = {"error": repr(e)[:300]}
+    return out
 
 
 def host_api_rate(torch, sh, Qh, k, steps=30):
@@ -143,7 +223,7 @@ def encode_rate(torch, device, kind="base", n_chunks=256, dtype="auto"):
     + HIP masked mean-pool/L2-norm, batch 32, ~480-token chunks truncated to 512 positions."""
     from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
     from comorag_amd.utils.config_utils import BaseConfig
-    from comorag_amd.utils.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+    from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
     tok, words = synthetic_wordpiece_tokenizer()
     cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_batch_size=32, embedding_model_dtype=dtype,
                      device=device.index or 0)
@@ -157,6 +237,15 @@ def encode_rate(torch, device, kind="base", n_chunks=256, dtype="auto"):
     dt = time.perf_counter() - t0
     return {"value": n_chunks / dt, "unit": "chunks/s", "model": f"BERT-{kind} shape, random init, {dtype}", "batch": 32,
             "chunks": n_chunks, "embedding_dim": int(out.shape[1])}
+
+
+def summarise(batch, steps, dt, prof, rows_gpu, dim):
+    ms = prof["total_ms"] / max(prof["launches"], 1)
+    return {"value": batch * steps / dt, "unit": "queries/s", "batch": batch, "ms_per_step": dt / steps * 1e3, "kernel_ms": ms,
+            "hbm_GBps": prof["bytes_per_launch"] / (ms * 1e-3) / 1e9 if ms else 0.0,
+            "frac_of_8TBps": prof["bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else 0.0,
+            "mfma_TFLOPs": 2.0 * batch * rows_gpu * dim / (ms * 1e-3) / 1e12 if ms else 0.0,
+            "exchange_ms": prof["exchange_ms"], "merge_ms": prof["merge_ms"]}
 
 
 def main():
@@ -182,96 +271,140 @@ def main():
     g.manual_seed(4321)
     q = torch.randn((args.batch, args.dim), generator=g, device=device, dtype=torch.float32)
     q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    qh = q.cpu().numpy()
 
-    sh = build_shard(torch, args, args.rows, rank, world, device)
-    dt, prof = run_steps(torch, dist, sh, q, args.k, args.steps, args.warmup, world, device)
-    qps = args.batch * args.steps / dt
-    scan_ms = prof["total_ms"] / max(prof["launches"], 1)
-    ach = prof["bytes_per_launch"] / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    # fp32 host copy of the corpus for the CPU legs (rank 0, N=1 only): needs rows*dim*4 bytes + slack
+    host = None
+    want_cpu = rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline
+    if want_cpu:
+        try:
+            import psutil
+            need = args.rows * args.dim * 4
+            if psutil.virtual_memory().available > need + (16 << 30):
+                host = np.empty((args.rows, args.dim), dtype=np.float32)
+        except Exception:
+            host = None
+    sh = build_shard(torch, args, args.rows, rank, world, device, host=host, timing=world > 1)
+    dt, prof, last = run_steps(torch, dist, sh, q, args.k, args.steps, args.warmup, world, device)
+    gpu_ids, gpu_sc, same = verify_last_batch(sh, last, qh, args.k)
+    head = summarise(args.batch, args.steps, dt, prof, len(sh), args.dim)
     out = {
-        "metric": "top-k queries/sec", "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} "
                                f"(north_star target config; corpus fixed, row-sharded over {world} GPU(s))",
                    "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
-                   "sharding": f"rows/{world}", "device": info["name"], "n_cu": info["n_cu"]},
-        "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                     "frac_of_achievable_6290": ach / HBM_ACHIEVABLE_GBS, "traffic": None,
-                     "kernel": "scan_kernel (fused MFMA scan + top-k)", "kernel_ms": scan_ms,
+                   "sharding": f"rows/{world}", "device": info["name"], "n_cu": info["n_cu"],
+                   "exchange": "none (1 shard)" if world == 1 else f"one packed-u64 all-gather per batch ({args.exchange} binding) + device key merge"},
+        "roofline": {"bound": "hbm", "achieved": head["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac_of_8TBps"],
+                     "frac_of_achievable_6290": head["hbm_GBps"] / HBM_ACHIEVABLE_GBS, "traffic": None,
+                     "kernel": "scan_kernel (fused MFMA scan + top-k)", "kernel_ms": head["kernel_ms"],
                      "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"],
                      "rows_per_gpu": len(sh)},
+        "verified": {"last_pipelined_batch_equals_synchronous_search": same},
     }
-    wide_extra = None
-    if rank == 0 and world == 1 and not args.no_extra and args.batch < 256:
-        # BASELINE config 3's batch size on this GPU's shard: 256 queries per step in ONE corpus pass
-        # (wide kernel: queries resident in registers); MFMA-bound rather than HBM-bound
+    if not same:
+        out["verified"]["error"] = "pipelined outputs differ from the synchronous search of the same batch"
+
+    # BASELINE config 3 as written: the same (sharded) corpus, batch 256 — one corpus pass of the wide kernel per batch
+    c3 = None
+    if not args.no_extra and args.batch != 256 and args.dim in (768, 1024):
         g2 = torch.Generator(device=device); g2.manual_seed(8765)
         q256 = torch.randn((256, args.dim), generator=g2, device=device, dtype=torch.float32)
         q256 = (q256 / q256.norm(dim=1, keepdim=True)).contiguous()
         torch.cuda.synchronize(device)
         steps_w = max(10, args.steps // 2)
-        dtw, profw = run_steps(torch, dist, sh, q256, args.k, steps_w, 3, 1, device)
-        msw = profw["total_ms"] / max(profw["launches"], 1)
-        wide_extra = {"value": 256 * steps_w / dtw, "unit": "queries/s", "batch": 256, "ms_per_step": dtw / steps_w * 1e3,
-                      "kernel_ms": msw, "kernel": "scan_wide_kernel (register-resident queries, LDS-DMA corpus ring)",
-                      "hbm_GBps": profw["bytes_per_launch"] / (msw * 1e-3) / 1e9 if msw else 0.0,
-                      "mfma_TFLOPs": 2.0 * 256 * len(sh) * args.dim / (msw * 1e-3) / 1e12 if msw else 0.0}
-    prof_file = os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")
+        dtw, profw, lastw = run_steps(torch, dist, sh, q256, args.k, steps_w, 3, world, device)
+        _, _, same_w = verify_last_batch(sh, lastw, q256.cpu().numpy(), args.k)
+        c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim)
+        c3["kernel"] = "scan_wide_kernel (256 queries resident in registers: 4 waves x 2 tiles, LDS-DMA corpus ring)"
+        c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
+        c3["last_pipelined_batch_equals_synchronous_search"] = same_w
+        c3["note"] = ("at the HBM/MFMA ridge and power-limited: a pure MFMA loop on this operand distribution sustains 1.45-1.83 PFLOP/s "
+                      "chip-wide (tools/probe/mfma_probe.hip), not 2.5")
+    if world > 1:
+        mine = {"rank": rank, "rows": len(sh), "batch64": {k_: head[k_] for k_ in ("kernel_ms", "exchange_ms", "merge_ms", "ms_per_step")},
+                "batch256": {k_: c3[k_] for k_ in ("kernel_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        out["per_rank"] = box
+    prof_file = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
     if os.path.exists(prof_file):
         pj = json.load(open(prof_file))
         w = pj.get("workload", {})
         if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (len(sh), args.dim, args.dtype, args.batch, args.k):
             out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)"
-    sh.local.close()
+            out["roofline"]["traffic_source"] = "profiles/r2_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)"
+    sh.close()
     del sh
     out["cpu_baseline"] = None
+    extra = {}
+    if c3 is not None:
+        extra["config3_batch256"] = c3
     if rank == 0 and world == 1 and not args.no_extra:
-        extra = {}
-        host_blocks = []
-        rows2 = min(args.rows, 1_000_000)
-        sh2 = build_shard(torch, args, rows2, 0, 1, device, keep_host=host_blocks)        # BASELINE config 2 when rows >= 1M
-        steps2 = max(args.steps, 100)
-        dt2, prof2 = run_steps(torch, dist, sh2, q, args.k, steps2, args.warmup, 1, device)
-        ms2 = prof2["total_ms"] / max(prof2["launches"], 1)
-        extra[f"config2_{rows2}_rows"] = {"value": args.batch * steps2 / dt2, "unit": "queries/s", "ms_per_step": dt2 / steps2 * 1e3,
-                                          "kernel_ms": ms2, "hbm_GBps": prof2["bytes_per_launch"] / (ms2 * 1e-3) / 1e9 if ms2 else 0.0,
-                                          "frac_of_8TBps": prof2["bytes_per_launch"] / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS if ms2 else 0.0}
-        Qh = q.cpu().numpy()
-        extra["host_buffer_api"] = host_api_rate(torch, sh2, Qh, args.k)
-        extra["host_buffer_api"]["note"] = f"PCIe-inclusive: {rows2} rows, H2D queries + D2H results + sync per call"
-        gpu_ids = sh2.local.search(Qh, args.k)[0]
-        try:        # complete ranking of one query (dense_passage_retrieval's all-N return): scan + device radix sort + D2H
-            sh2.local.sorted_scores(Qh[:1])
-            t0 = time.perf_counter()
-            for i in range(10):
-                sh2.local.sorted_scores(Qh[i % len(Qh):i % len(Qh) + 1])
-            dtr = (time.perf_counter() - t0) / 10
-            x1 = sh2.local.scores(Qh[:1])[0]
-            t0 = time.perf_counter()
-            np.argsort(x1)[::-1]
-            extra["full_ranking_one_query"] = {"rows": rows2, "ms_per_query": dtr * 1e3, "host_argsort_ms": (time.perf_counter() - t0) * 1e3,
-                                               "note": "PCIe-inclusive: N int64 ids + N fp32 scores copied back"}
-        except Exception as e:
-            extra["full_ranking_one_query"] = {"error": repr(e)[:300]}
-        sh2.local.close()
+        from comorag_amd.sharded import ShardedIndex
+        # BASELINE config 2 (1 M rows) and one 8-GPU shard of config 3 (1.25 M rows) on this GPU
+        for name, rows2, batches in (("config2", min(args.rows, 1_000_000), (args.batch,)), ("config3_one_of_8_shards", min(args.rows, 1_250_000), (args.batch, 256))):
+            sh2 = build_shard(torch, args, rows2, 0, 1, device)
+            for b2 in batches:
+                qq = q if b2 == args.batch else q256
+                steps2 = max(args.steps, 100)
+                dt2, prof2, _ = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device)
+                extra[f"{name}_{rows2}_rows_batch{b2}"] = summarise(b2, steps2, dt2, prof2, rows2, args.dim)
+            if name == "config2":
+                extra["host_buffer_api"] = host_api_rate(torch, sh2, qh, args.k)
+                extra["host_buffer_api"]["note"] = f"PCIe-inclusive: {rows2} rows, H2D queries + D2H results + sync per call"
+                try:        # complete ranking of one query (dense_passage_retrieval's all-N return): scan + device radix sort + D2H
+                    sh2.local.sorted_scores(qh[:1])
+                    t0 = time.perf_counter()
+                    for i in range(10):
+                        sh2.local.sorted_scores(qh[i % len(qh):i % len(qh) + 1])
+                    dtr = (time.perf_counter() - t0) / 10
+                    x1 = sh2.local.scores(qh[:1])[0]
+                    t0 = time.perf_counter()
+                    np.argsort(x1)[::-1]
+                    extra["full_ranking_one_query"] = {"rows": rows2, "ms_per_query": dtr * 1e3, "host_argsort_ms": (time.perf_counter() - t0) * 1e3,
+                                                       "note": "PCIe-inclusive: N int64 ids + N fp32 scores copied back"}
+                except Exception as e:
+                    extra["full_ranking_one_query"] = {"error": repr(e)[:300]}
+            sh2.close()
+        s64 = extra.get(f"config3_one_of_8_shards_{min(args.rows, 1_250_000)}_rows_batch{args.batch}")
+        s256 = extra.get(f"config3_one_of_8_shards_{min(args.rows, 1_250_000)}_rows_batch256")
+        if s64 and s256 and c3:
+            extra["projected_8gpu"] = {"projected": True,
+                                       "basis": "step time of ONE 1.25 M-row shard measured on this GPU vs the 10 M-row step above; the exchange (10-40 KiB per rank) "
+                                                "runs on the post stream under the next scan and is not included",
+                                       "batch64_speedup": head["ms_per_step"] / s64["ms_per_step"], "batch256_speedup": c3["ms_per_step"] / s256["ms_per_step"]}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, np.concatenate(host_blocks), Qh, gpu_ids)
-        del host_blocks
+            if host is None:                    # not enough host RAM for the full fp32 copy: first 1 M rows, scaled
+                n1 = min(args.rows, 1_000_000)
+                host = np.empty((n1, args.dim), dtype=np.float32)
+                at = 0
+                for blk in gen_rows_dev(torch, 0, n1, args.dim, device):
+                    host[at:at + len(blk)] = blk.cpu().numpy(); at += len(blk)
+                full = n1 == args.rows
+                sh3 = build_shard(torch, args, n1, 0, 1, device)
+                ids_for_recall = sh3.local.search(qh, args.k)[0]
+                sh3.close()
+            else:
+                full, ids_for_recall = True, gpu_ids
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, host, qh, ids_for_recall, full)
+        del host
         try:
             extra["corpus_embed"] = encode_rate(torch, device, "base", 256, "auto")
             extra["corpus_embed_bf16"] = encode_rate(torch, device, "base", 256, "bf16")
         except Exception as e:  # the headline line must still print
             extra["corpus_embed"] = {"error": repr(e)[:300]}
-        if wide_extra is not None:
-            extra["batch256_one_pass"] = wide_extra
+    if extra:
         out["extra"] = extra
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not same:
+        raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
 
 
 if __name__ == "__main__":

@@ -254,3 +254,26 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 def f16_round(x: np.ndarray) -> np.ndarray:
     return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def retrieve_knn_torch_cpu(query_vecs, key_vecs, k: int = 2047, query_batch_size: int = 1000, key_batch_size: int = 10000):
+    """utils/embed_utils.py:8-97 with the reference's own primitives forced onto the CPU (torch.mm + torch.topk per
+    key block, concat, final torch.topk) — the batched CPU comparator of bench.py's ``cpu_baseline`` (BASELINE.md §3 ii).
+    Returns (indices [nq, k'], scores [nq, k']); tie order is torch.topk's (unspecified), so parity checks use
+    ``retrieve_knn`` above, timing uses this one."""
+    import torch
+    q = torch.nn.functional.normalize(torch.as_tensor(np.asarray(query_vecs, dtype=np.float32)), dim=1)      # :27-31
+    kx = torch.nn.functional.normalize(torch.as_tensor(np.asarray(key_vecs, dtype=np.float32)), dim=1)
+    out_i, out_s = [], []
+    for qs in range(0, len(q), query_batch_size):                                                           # :40-78
+        qb = q[qs:qs + query_batch_size]
+        cs, ci = [], []
+        for ks in range(0, len(kx), key_batch_size):
+            kb = kx[ks:ks + key_batch_size]
+            sim = torch.mm(qb, kb.T)
+            s, i = torch.topk(sim, min(k, kb.shape[0]), dim=1)
+            cs.append(s); ci.append(i + ks)
+        cs, ci = torch.cat(cs, dim=1), torch.cat(ci, dim=1)
+        s, o = torch.topk(cs, min(k, cs.shape[1]), dim=1)
+        out_s.append(s); out_i.append(torch.gather(ci, 1, o))
+    return torch.cat(out_i).numpy(), torch.cat(out_s).numpy()

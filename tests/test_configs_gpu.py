@@ -65,7 +65,7 @@ def test_config5_encode_then_search_then_rescore():
     from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
     from comorag_amd.index import DenseIndex
     from comorag_amd.utils.config_utils import BaseConfig
-    from comorag_amd.utils.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+    from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
     tok, words = synthetic_wordpiece_tokenizer(8000)
     cfg = BaseConfig(embedding_model_name="bge-large-random-init", embedding_batch_size=32, embedding_model_dtype="fp16")
     em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert("large", vocab_size=len(tok)), tokenizer=tok)

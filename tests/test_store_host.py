@@ -189,7 +189,7 @@ def test_tokenize_batch_equals_the_reference_tokenizer_call():
     return_tensors="pt")`): same keys, int64 tensors, padding to the longest prompt, truncation."""
     import torch
     from comorag_amd.embedding_model.bge import tokenize_batch
-    from comorag_amd.utils.synthetic import synthetic_chunks, synthetic_wordpiece_tokenizer
+    from tools.synthetic import synthetic_chunks, synthetic_wordpiece_tokenizer
     tok, words = synthetic_wordpiece_tokenizer()
     chunks = synthetic_chunks(words, 8)
     texts = chunks[:5] + ["", "a", chunks[5][:50], "   ", chunks[6] * 3]

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel, tokenize_batch
 from comorag_amd.utils.config_utils import BaseConfig
-from comorag_amd.utils.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
 tok, words = synthetic_wordpiece_tokenizer()
 chunks = synthetic_chunks(words, 256)
 t0 = time.perf_counter(); [tok(chunks[:32], padding=True, truncation=True, max_length=512, return_tensors="pt") for _ in range(4)]; t1 = time.perf_counter()

@@ -1,5 +1,6 @@
 """Synthetic stand-ins for assets that are not on disk (no network): a random-init BERT encoder of
-BGE-base / BGE-large shape and a WordPiece tokenizer over a generated vocabulary.  Used by bench.py
+BGE-base / BGE-large shape and a WordPiece tokenizer over a generated vocabulary.  Bench / test data, not
+part of the product package (comorag_amd/).  Used by bench.py
 for the corpus-embed throughput figure; NOT a model — random weights give meaningless vectors."""
 from __future__ import annotations
 
