@@ -80,10 +80,28 @@ struct Workspace {
     DevBuf qfrag, lists, cnt, mm, flag, tau, s_lists, s_cnt, s_mm;
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
+    // synchronous search: queries in, (ids | scores | min | max | non-finite flag) out through ONE pinned host buffer and
+    // one copy each way — five pageable D2H copies cost more than the search of a small corpus
+    DevBuf d_pack;
+    int* flag_ptr = nullptr;     // the non-finite-query flag the kernels set: flag.p, or the head of d_pack for the host API
+    void* h_pin = nullptr;
+    size_t h_pin_cap = 0;
+    hipError_t ensure_pin(size_t need) {
+        if (need <= h_pin_cap) return hipSuccess;
+        if (h_pin) { hipError_t e = hipHostFree(h_pin); if (e != hipSuccess) return e; h_pin = nullptr; h_pin_cap = 0; }
+        const size_t want = std::max(need, h_pin_cap * 2);
+        hipError_t e = hipHostMalloc(&h_pin, want, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        h_pin_cap = want;
+        return hipSuccess;
+    }
     void release() {
         qfrag.release(); lists.release(); cnt.release(); mm.release(); flag.release(); tau.release();
         s_lists.release(); s_cnt.release(); s_mm.release();
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
+        d_pack.release();
+        if (h_pin) (void)hipHostFree(h_pin);
+        h_pin = nullptr; h_pin_cap = 0;
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -121,6 +139,7 @@ struct cmr_index {
     int force_grid = 0;      // CMR_SCAN_GRID
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
+    int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch path for corpora of <= 1024 rows
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
     int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
@@ -163,6 +182,15 @@ int check_device(int device_id) {
         if (ok.size() <= (size_t)device_id) ok.resize((size_t)device_id + 1, 0);
         ok[device_id] = 1;
     }
+    return CMR_OK;
+}
+
+// the workspace's non-finite flag, allocated and zeroed on first use
+int arm_flag(Workspace* ws, hipStream_t s) {
+    if (ws->flag_ptr) return CMR_OK;
+    HIP_TRY(ws->flag.ensure(sizeof(int)));
+    HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
+    ws->flag_ptr = (int*)ws->flag.p;
     return CMR_OK;
 }
 
@@ -274,11 +302,9 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
                  int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false) {
     CmrScanGeom g;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-    if (!ws->flag.p) {   // zeroed once; check_query_flag() re-arms it after reporting
-        HIP_TRY(ws->flag.ensure(sizeof(int)));
-        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), sp));
-    }
-    int rc = make_geom(idx, nqp, k, true, &g);
+    int rc = arm_flag(ws, sp);   // zeroed once; the reader re-arms it after reporting
+    if (rc) return rc;
+    rc = make_geom(idx, nqp, k, true, &g);
     if (rc) return rc;
     const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
     // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
@@ -366,7 +392,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(ws->s_mm.ensure((size_t)Ws * NQ * 8));
     }
     HIP_TRY(ws->tau.ensure((size_t)2 * NQ * 8));
-    HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev, nqp, idx->dim, idx->dpad, tiles, ws->qfrag.p, (int*)ws->flag.p, sp));
+    HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev, nqp, idx->dim, idx->dpad, tiles, ws->qfrag.p, ws->flag_ptr, sp));
     CmrScanArgs a{};
     a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
     a.nq = nqp;
@@ -426,6 +452,16 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
                    float* min_dev, float* max_dev) {
     if (k > CMR_MAX_K) return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
+    {   // tiny corpus: one single-workgroup launch does packing, scan, selection and min/max
+        const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+        if (!idx->no_tiny && npanels <= 32 && nq <= 16 && idx->n > 0) {
+            { int rc_ = arm_flag(ws, ws->stream); if (rc_) return rc_; }
+            HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels)));
+            HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, (float*)ws->d_out.p,
+                                           ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, ws->stream));
+            return CMR_OK;
+        }
+    }
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
     for (int q0 = 0; q0 < nq;) {
@@ -503,17 +539,14 @@ int scores_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, fl
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-    if (!ws->flag.p) {
-        HIP_TRY(ws->flag.ensure(sizeof(int)));
-        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
-    }
+    { int rc_ = arm_flag(ws, s); if (rc_) return rc_; }
     for (int q0 = 0; q0 < nq; q0 += per_pass) {
         const int nqp = std::min(per_pass, nq - q0);
         int rc = make_geom(idx, nqp, 1, false, &g);
         if (rc) return rc;
         HIP_TRY(ws->qfrag.ensure((size_t)g.nqt * g.ks * 1024));
         HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev + (size_t)q0 * idx->dim, nqp, idx->dim, idx->dpad, g.nqt, ws->qfrag.p,
-                                        (int*)ws->flag.p, s));
+                                        ws->flag_ptr, s));
         CmrScanArgs a{};
         a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = 1;
         a.scores = out_dev + (size_t)q0 * ld; a.ld = ld; a.nq = nqp;
@@ -524,10 +557,10 @@ int scores_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, fl
 
 int check_query_flag(Workspace* ws) {
     int h = 0;
-    HIP_TRY(hipMemcpyAsync(&h, ws->flag.p, sizeof(int), hipMemcpyDeviceToHost, ws->stream));
+    HIP_TRY(hipMemcpyAsync(&h, ws->flag_ptr, sizeof(int), hipMemcpyDeviceToHost, ws->stream));
     HIP_TRY(hipStreamSynchronize(ws->stream));
     if (h) {
-        HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), ws->stream));
+        HIP_TRY(hipMemsetAsync(ws->flag_ptr, 0, sizeof(int), ws->stream));
         return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
     }
     return CMR_OK;
@@ -622,6 +655,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
+    idx->no_tiny = env_int("CMR_SCAN_NO_TINY", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
     idx->sample_div = std::max(2, env_int("CMR_SAMPLE_DIV", 32));
     idx->sample_maxmul = std::max(0, env_int("CMR_SAMPLE_MAXMUL", 0));
@@ -788,13 +822,13 @@ int32_t cmr_index_query_status(cmr_index_t* idx, int32_t* nonfinite) {
         for (auto& kv : idx->stream_ws) wss.push_back(kv.second);
     }
     for (Workspace* ws : wss) {
-        if (!ws->flag.p) continue;
+        if (!ws->flag_ptr) continue;
         if (ws->stream || !ws->own_stream) HIP_TRY(hipStreamSynchronize(ws->stream));
         int h = 0;
-        HIP_TRY(hipMemcpy(&h, ws->flag.p, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&h, ws->flag_ptr, sizeof(int), hipMemcpyDeviceToHost));
         if (h) {
             *nonfinite = 1;
-            HIP_TRY(hipMemset(ws->flag.p, 0, sizeof(int)));
+            HIP_TRY(hipMemset(ws->flag_ptr, 0, sizeof(int)));
         }
     }
     return CMR_OK;
@@ -824,20 +858,37 @@ int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k
     if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
     struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
     hipStream_t s = ws->stream;
-    HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
-    HIP_TRY(ws->d_ids.ensure((size_t)nq * k * 8));
-    HIP_TRY(ws->d_scores.ensure((size_t)nq * k * 4));
-    HIP_TRY(ws->d_min.ensure((size_t)nq * 4));
-    HIP_TRY(ws->d_max.ensure((size_t)nq * 4));
-    HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
-    rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)ws->d_ids.p, (float*)ws->d_scores.p,
-                        (float*)ws->d_min.p, (float*)ws->d_max.p);
+    // packed device buffer [flag (8 B) | ids nq*k i64 | scores nq*k f32 | min nq | max nq] and its pinned host twin; the
+    // queries go through the pinned buffer too (a pageable H2D is staged by the runtime anyway)
+    const size_t o_ids = 8, o_sc = o_ids + (size_t)nq * k * 8, o_min = o_sc + (size_t)nq * k * 4, o_max = o_min + (size_t)nq * 4,
+                 out_bytes = o_max + (size_t)nq * 4, q_bytes = (size_t)nq * idx->dim * 4;
+    HIP_TRY(ws->d_q.ensure(q_bytes));
+    if (out_bytes > ws->d_pack.cap || !ws->d_pack.p) {        // (re)allocation moves the flag: re-arm it at the new place
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(ws->d_pack.ensure(std::max<size_t>(out_bytes, 4096)));
+        HIP_TRY(hipMemsetAsync(ws->d_pack.p, 0, 8, s));
+        ws->flag_ptr = (int*)ws->d_pack.p;
+    }
+    HIP_TRY(ws->ensure_pin(std::max(out_bytes, q_bytes)));
+    memcpy(ws->h_pin, q, q_bytes);
+    HIP_TRY(hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s));
+    char* pk = (char*)ws->d_pack.p;
+    rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max));
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
-    HIP_TRY(hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
-    if (out_min) HIP_TRY(hipMemcpyAsync(out_min, ws->d_min.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    if (out_max) HIP_TRY(hipMemcpyAsync(out_max, ws->d_max.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    return check_query_flag(ws);
+    HIP_TRY(hipMemcpyAsync(ws->h_pin, pk, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const char* hp = (const char*)ws->h_pin;
+    int flagged = 0;
+    memcpy(&flagged, hp, sizeof(int));
+    if (flagged) {
+        HIP_TRY(hipMemsetAsync(ws->flag_ptr, 0, sizeof(int), s));
+        return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+    }
+    memcpy(out_ids, hp + o_ids, (size_t)nq * k * 8);
+    memcpy(out_scores, hp + o_sc, (size_t)nq * k * 4);
+    if (out_min) memcpy(out_min, hp + o_min, (size_t)nq * 4);
+    if (out_max) memcpy(out_max, hp + o_max, (size_t)nq * 4);
+    return CMR_OK;
 }
 
 int32_t cmr_index_scores_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, float* out_dev, int64_t ld, void* stream) {

@@ -374,6 +374,116 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// Tiny corpora (<= 32 panels = 1024 rows, <= 16 queries; ComoRAG's per-question calls see 6 chunks to a few hundred facts, one query at a
+// time): the whole search in ONE launch of ONE workgroup — query packing (fp32 -> MFMA B-operands in LDS, non-finite
+// check), the MFMA scan (wave w takes panels w, w+8, ..; same block order, hence the same fp32 chains and bit-identical
+// scores, as scan_kernel), per-query selection (wave w takes queries w, w+8, ..: k rounds of arg-max over the <= 16 keys
+// a lane holds) and min / max.  The general path costs 3 launches there (pack, scan, merge) on 108-126 us per call.
+template <int DT>
+__global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict__ corpus, const float* __restrict__ q, int nq, int dim, int ks_total,
+                                                          int nrows, int npanels, int k, long long id_base, float* __restrict__ scratch,
+                                                          int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
+                                                          float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqt = (nq + 31) / 32;
+    bool bad = false;
+    for (int i = tid; i < nqt * ks_total * 64; i += 512) {
+        const int l = i & 63, ks = (i >> 6) % ks_total, t = (i >> 6) / ks_total;
+        const int qi = t * 32 + (l & 31);
+        qf[i] = cmr_pack_slot<DT>(qi < nq ? q + (size_t)qi * dim : nullptr, dim, ks, l, bad);
+    }
+    if (bad) atomicOr(flag, 1);
+    __syncthreads();
+    const int ld = npanels * CMR_PANEL_ROWS;
+    const v4u* qv = reinterpret_cast<const v4u*>(qf);
+    for (int p = wave; p < npanels; p += 8) {
+        for (int t = 0; t < nqt; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int ks0 = 0; ks0 < ks_total; ks0 += 16) {          // sixteen 1-KiB blocks in flight per wave (ks_total is a multiple of 8)
+                v4u buf[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) buf[j] = corpus[((size_t)p * ks_total + (ks0 + j < ks_total ? ks0 + j : ks_total - 1)) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (ks0 + j < ks_total) acc = CmrBlk<DT>::mma(buf[j], qv[(t * ks_total + ks0 + j) * 64 + lane], acc);   // D[row][query], k order
+            }
+            const int qi = t * 32 + (lane & 31);
+            if (qi < nq) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scratch[(size_t)qi * ld + p * CMR_PANEL_ROWS + cmr_acc_row(r, lane)] = acc[r];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int qi = wave; qi < nq; qi += 8) {
+        u64 key[16];
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int row = lane + 64 * j;
+            key[j] = 0ull;
+            if (row < nrows) {
+                const float v = scratch[(size_t)qi * ld + row];
+                mn = fminf(mn, v); mx = fmaxf(mx, v);
+                if (v == v) key[j] = cmr_make_key(v, (unsigned)row);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if (lane == 0) { if (out_min) out_min[qi] = mn; if (out_max) out_max[qi] = mx; }
+        for (int round = 0; round < k; ++round) {
+            u64 best = 0ull;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
+            u64 wb = best;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+            if (wb != 0ull && best == wb) {          // keys are unique: exactly one lane, one slot
+#pragma unroll
+                for (int j = 0; j < 16; ++j) key[j] = key[j] == wb ? 0ull : key[j];
+            }
+            if (lane == 0) {
+                out_ids[(size_t)qi * k + round] = wb ? (int64_t)cmr_key_row(wb) + id_base : -1;
+                out_scores[(size_t)qi * k + round] = wb ? cmr_key_score(wb) : -__builtin_inff();
+            }
+        }
+    }
+}
+
+size_t cmr_tiny_scratch_bytes(int nq, int npanels) { return (size_t)nq * npanels * CMR_PANEL_ROWS * sizeof(float); }
+
+hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
+                                  float* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, hipStream_t s) {
+    const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
+    const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
+    const int nqt = (nq + 31) / 32;
+    const size_t lds = (size_t)nqt * ks * 1024;
+    if (npanels > 32 || nq > 16 || lds > 160 * 1024) return hipErrorInvalidValue;
+    const v4u* c = reinterpret_cast<const v4u*>(corpus);
+#define TS(DT)                                                                                                                       \
+    {                                                                                                                                \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                               \
+        hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(1), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scratch, out_ids, \
+                           out_scores, out_min, out_max, flag);                                                                      \
+    }
+    switch (dtype) {
+        case CMR_DT_BF16: TS(CMR_DT_BF16) break;
+        case CMR_DT_F16: TS(CMR_DT_F16) break;
+        case CMR_DT_F32: TS(CMR_DT_F32) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TS
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Large-k selection over a materialised score matrix: one workgroup per row of scores [nq, ld]
 // picks the k (<= 4096) best (score desc, column asc) — the device half of retrieve_knn's
 // torch.topk(k = 2047) (utils/embed_utils.py:56-78) once cmr_index_scores_dev produced the block.

@@ -57,6 +57,19 @@ def test_small_shapes(dtype, n):
     _check(dtype, X, Q, 5)
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (6, 1, 5), (6, 3, 20), (33, 8, 20), (1000, 1, 20), (1024, 16, 20), (1024, 9, 128), (700, 16, 7)])
+def test_tiny_single_launch_path_equals_general_path(dtype, n, nq, k):
+    """<= 1024 rows: one single-workgroup launch (tiny_search_kernel) — must equal the oracle and, bit for bit, the
+    general pack / scan / merge path (CMR_SCAN_NO_TINY=1)."""
+    X, Q = _mk(n, 768 if dtype != "f32" else 200, nq, seed=n + nq)
+    if n > 40:
+        X[n // 2] = X[3]; Q[0] = X[3]                            # a tie, and an exact hit
+    a_ids, a_sc = _check(dtype, X, Q, k)
+    b_ids, b_sc = _check(dtype, X, Q, k, env={"CMR_SCAN_NO_TINY": "1"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+
+
 @pytest.mark.parametrize("dtype,d", [("bf16", 8), ("bf16", 128), ("bf16", 768), ("bf16", 1024), ("f16", 1024),
                                      ("f32", 768), ("f32", 100), ("bf16", 200)])
 def test_dims(dtype, d):
