@@ -29,7 +29,7 @@ STAMP = os.path.join(LIBDIR, "build_stamp.json")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip"]
+SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip"]
 HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 
 _KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
@@ -218,7 +218,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     "        }\n"
                     "    return any;\n"
                     "}\n")
-        for src in ("aux_kernels.hip", "api.hip", "comm.hip"):
+        for src in ("aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip"):
             o = os.path.join(tmp, src.replace(".hip", ".o"))
             _run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", o], cwd=tmp)
             objs.append(o)

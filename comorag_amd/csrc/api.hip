@@ -608,6 +608,51 @@ int append_from_device(cmr_index* idx, const float* rows_dev, long long n, hipSt
 
 }  // namespace
 
+// ---- for ppr.hip: one host query -> N raw scores in the workspace's device buffer, index lock + workspace kept until release
+namespace { thread_local Workspace* tl_scores_ws = nullptr; }
+
+int cmr_index_scores_to_device(cmr_index_t* idx, const float* q_host, float** scores_dev, long long* n, void** stream) {
+    if (!idx || !q_host || !scores_dev || !n || !stream) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (tl_scores_ws) return fail(CMR_ERR_INVALID, "nested cmr_index_scores_to_device on one thread");
+    idx->mu.lock_shared();
+    int rc = set_device(idx->device);
+    Workspace* ws = rc ? nullptr : acquire_ws(idx, nullptr, false);
+    if (!rc && !ws) rc = fail(CMR_ERR_HIP, "could not create a workspace stream");
+    if (!rc) {
+        hipStream_t s = ws->stream;
+        auto body = [&]() -> int {
+            const size_t q_bytes = (size_t)idx->dim * 4;
+            HIP_TRY(ws->d_q.ensure(q_bytes));
+            HIP_TRY(ws->d_out.ensure(std::max<size_t>((size_t)idx->n * 4, 8)));
+            HIP_TRY(ws->ensure_pin(q_bytes));
+            memcpy(ws->h_pin, q_host, q_bytes);
+            HIP_TRY(hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s));
+            if (idx->n == 0) return CMR_OK;
+            return scores_enqueue(idx, ws, (const float*)ws->d_q.p, 1, (float*)ws->d_out.p, idx->n);
+        };
+        rc = body();
+        if (rc) (void)hipStreamSynchronize(s);
+    }
+    if (rc) {
+        if (ws) release_ws(idx, ws);
+        idx->mu.unlock_shared();
+        return rc;
+    }
+    tl_scores_ws = ws;
+    *scores_dev = (float*)ws->d_out.p; *n = idx->n; *stream = (void*)ws->stream;
+    return CMR_OK;
+}
+
+int cmr_index_scores_release(cmr_index_t* idx) {
+    Workspace* ws = tl_scores_ws;
+    if (!idx || !ws) return CMR_OK;
+    tl_scores_ws = nullptr;
+    int rc = ws->flag_ptr ? check_query_flag(ws) : CMR_OK;
+    release_ws(idx, ws);
+    idx->mu.unlock_shared();
+    return rc;
+}
+
 // ============================================================================================
 extern "C" {
 

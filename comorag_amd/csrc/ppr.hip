@@ -1,0 +1,330 @@
+// Personalised PageRank seeded by dense-retrieval scores, on the device.
+//
+// Replaces, for one query, the tail of ComoRAG.graph_search_with_fact_entities (src/comorag/ComoRAG.py:1034-1044: all N
+// (passage id, normalised DPR score) pairs are copied to the host, scattered one by one into `passage_weights` through
+// passage_node_keys -> node_name_to_vertex_idx) and ComoRAG.run_ppr (:1086-1105: igraph's prpack personalised PageRank,
+// undirected, edge attribute 'weight', damping 0.5, reset = node weights; then doc_scores = pagerank[passage_node_idxs]).
+// Here the N scores never leave HBM: scan -> global min / max -> scatter of min_max(score) * passage_node_weight into the
+// reset vector through the passage-row -> vertex map -> power iteration on a CSR copy of the graph -> gather of the
+// passage vertices; only n_passages doubles come back (8 * n_passages bytes instead of 12 * N + the igraph call).
+//
+// Semantics restated from igraph_personalized_pagerank(PRPACK): reset vector r (negative / NaN entries -> 0, then divided
+// by its sum); transition i -> j with probability w_ij / s_i (s_i = sum of i's incident weights; undirected = both
+// directions); a vertex without edges jumps according to r; x = d * (P^T x + (sum of dangling x) * r) + (1 - d) * r.
+// prpack solves this system directly to ~1e-10; a power iteration contracts by d per step, so ceil(log(tol/2)/log(d))
+// steps reach tol in the 1-norm (43 steps for tol = 1e-12 at d = 0.5).  fp64 throughout, fixed summation order
+// (pull-style CSR rows, block-ordered reductions): results are reproducible bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/comorag_hip.h"
+#include "cmr_kernels.h"
+
+int cmr_fail(int code, const char* fmt, ...);                                                                     // api.hip
+// api.hip: scores of ONE host query into a device buffer of the index's workspace (shared index lock held, workspace
+// reserved for the calling thread) until cmr_index_scores_release, which also reports a non-finite query
+int cmr_index_scores_to_device(cmr_index_t* idx, const float* q_host, float** scores_dev, long long* n, void** stream);
+int cmr_index_scores_release(cmr_index_t* idx);
+
+struct cmr_graph {
+    int device = 0;
+    long long nv = 0, ne = 0;          // vertices, directed CSR entries (2 x undirected edges, self-loops once)
+    long long* rowptr = nullptr;       // [nv + 1]
+    int* col = nullptr;                // [ne]
+    double* wnorm = nullptr;           // [ne]  w_ij / s_j of the SOURCE j of the pulled term (so y_i = sum_j wnorm * x_j)
+    int* dangling = nullptr;           // vertices with no incident weight
+    long long n_dangling = 0;
+    int* vertex_of_row = nullptr;      // passage row -> vertex
+    long long n_rows = 0;
+    double *reset = nullptr, *x = nullptr, *y = nullptr, *red = nullptr, *out = nullptr;
+    float2* mm = nullptr;              // per-block (min, max) partials of the raw scores
+    int* seed_v = nullptr;
+    double* seed_w = nullptr;
+    long long seed_cap = 0;
+};
+
+#define PPR_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return cmr_fail(e_ == hipErrorOutOfMemory ? CMR_ERR_OOM : CMR_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ kernels
+#define PPR_T 256
+#define PPR_RED_BLOCKS 256
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < PPR_T / 64; ++w) t += sh[w];      // fixed order
+    __syncthreads();
+    return t;
+}
+
+// per-block partial (min, max) of the raw scores
+__global__ __launch_bounds__(PPR_T) void ppr_minmax_partial_kernel(const float* __restrict__ s, long long n, float2* __restrict__ part) {
+    __shared__ float smn[PPR_T / 64], smx[PPR_T / 64];
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (long long i = (long long)blockIdx.x * PPR_T + threadIdx.x; i < n; i += (long long)gridDim.x * PPR_T) { const float v = s[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PPR_T / 64; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); }
+        part[blockIdx.x] = make_float2(mn, mx);
+    }
+}
+
+// reset[vertex_of_row[i]] = min_max_normalize(scores)[i] * pnw  (the reference's fp32 formula, utils/misc_utils.py:141-150;
+// applied twice there (ComoRAG.py:963, :1035) — the second application is the identity), then the product in fp64 as
+// numpy does for float32 * python float
+__global__ __launch_bounds__(PPR_T) void ppr_scatter_kernel(const float* __restrict__ s, long long n, const float2* __restrict__ part, int nparts,
+                                                            const int* __restrict__ vertex_of_row, double pnw, double* __restrict__ reset) {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    for (int b = 0; b < nparts; ++b) { mn = fminf(mn, part[b].x); mx = fmaxf(mx, part[b].y); }
+    const float range = mx - mn;
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i >= n) return;
+    const float norm = range == 0.0f ? 1.0f : (s[i] - mn) / range;
+    reset[vertex_of_row[i]] = (double)norm * pnw;
+}
+
+__global__ __launch_bounds__(PPR_T) void ppr_seed_kernel(const int* __restrict__ v, const double* __restrict__ w, long long n, double* __restrict__ reset) {
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i < n) reset[v[i]] += w[i];          // phrase vertices and passage vertices are disjoint sets (ComoRAG.py:1045)
+}
+
+// reset <- max(reset, 0) with NaN -> 0 (ComoRAG.py:1090); partial sums per block
+__global__ __launch_bounds__(PPR_T) void ppr_clean_sum_kernel(double* __restrict__ r, long long nv, double* __restrict__ part) {
+    __shared__ double sh[PPR_T / 64];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * PPR_T + threadIdx.x; i < nv; i += (long long)gridDim.x * PPR_T) {
+        double v = r[i];
+        if (!(v >= 0.0)) v = 0.0;
+        r[i] = v;
+        acc += v;
+    }
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// r <- r / sum, x <- r
+__global__ __launch_bounds__(PPR_T) void ppr_normalise_kernel(double* __restrict__ r, double* __restrict__ x, long long nv, const double* __restrict__ part, int nparts) {
+    double tot = 0.0;
+    for (int b = 0; b < nparts; ++b) tot += part[b];
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i >= nv) return;
+    const double v = tot > 0.0 ? r[i] / tot : 1.0 / (double)nv;
+    r[i] = v;
+    x[i] = v;
+}
+
+// mass sitting on vertices without edges (single block, fixed order)
+__global__ __launch_bounds__(PPR_T) void ppr_dangling_kernel(const double* __restrict__ x, const int* __restrict__ dang, long long nd, double* __restrict__ out) {
+    __shared__ double sh[PPR_T / 64];
+    double acc = 0.0;
+    for (long long i = threadIdx.x; i < nd; i += PPR_T) acc += x[dang[i]];
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// y_i = d * (sum_{j in N(i)} wnorm_ij * x_j + D * r_i) + (1 - d) * r_i      (one thread per vertex: graph rows are short)
+__global__ __launch_bounds__(PPR_T) void ppr_step_kernel(const long long* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ wnorm,
+                                                         const double* __restrict__ x, const double* __restrict__ r, const double* __restrict__ dmass,
+                                                         double d, long long nv, double* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i >= nv) return;
+    double acc = 0.0;
+    for (long long e = rowptr[i]; e < rowptr[i + 1]; ++e) acc += wnorm[e] * x[col[e]];
+    const double D = dmass ? dmass[0] : 0.0;
+    y[i] = d * (acc + D * r[i]) + (1.0 - d) * r[i];
+}
+
+__global__ __launch_bounds__(PPR_T) void ppr_gather_kernel(const double* __restrict__ x, const int* __restrict__ vertex_of_row, long long n, double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i < n) out[i] = x[vertex_of_row[i]];
+}
+
+static unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + PPR_T - 1) / PPR_T); }
+
+// reset (device, raw) -> normalised -> power iteration -> x holds the stationary vector
+static int ppr_iterate(cmr_graph* g, double damping, double tol, int max_iter, hipStream_t s, int* iters_out) {
+    const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(g->nv));
+    hipLaunchKernelGGL(ppr_clean_sum_kernel, dim3(nparts), dim3(PPR_T), 0, s, g->reset, g->nv, g->red);
+    hipLaunchKernelGGL(ppr_normalise_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, g->reset, g->x, g->nv, g->red, nparts);
+    int iters = (int)std::ceil(std::log(std::max(tol, 1e-300) / 2.0) / std::log(std::min(std::max(damping, 1e-12), 1.0 - 1e-12)));
+    iters = std::max(1, std::min(iters, max_iter > 0 ? max_iter : 1000));
+    if (damping <= 0.0) iters = 1;
+    double *x = g->x, *y = g->y;
+    for (int it = 0; it < iters; ++it) {
+        if (g->n_dangling) hipLaunchKernelGGL(ppr_dangling_kernel, dim3(1), dim3(PPR_T), 0, s, x, g->dangling, g->n_dangling, g->red + PPR_RED_BLOCKS);
+        hipLaunchKernelGGL(ppr_step_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, x, g->reset,
+                           g->n_dangling ? g->red + PPR_RED_BLOCKS : nullptr, damping, g->nv, y);
+        std::swap(x, y);
+    }
+    if (x != g->x) std::swap(g->x, g->y);          // g->x = result
+    if (iters_out) *iters_out = iters;
+    PPR_TRY(hipGetLastError());
+    return CMR_OK;
+}
+
+static int ensure_seeds(cmr_graph* g, long long n) {
+    if (n <= g->seed_cap) return CMR_OK;
+    if (g->seed_v) PPR_TRY(hipFree(g->seed_v));
+    if (g->seed_w) PPR_TRY(hipFree(g->seed_w));
+    g->seed_v = nullptr; g->seed_w = nullptr; g->seed_cap = 0;
+    PPR_TRY(hipMalloc((void**)&g->seed_v, (size_t)n * 4));
+    PPR_TRY(hipMalloc((void**)&g->seed_w, (size_t)n * 8));
+    g->seed_cap = n;
+    return CMR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ C-ABI
+extern "C" {
+
+int32_t cmr_graph_create(int32_t device_id, int64_t n_vertices, int64_t n_edges, const int32_t* src, const int32_t* dst, const double* weight,
+                         cmr_graph_t** out) {
+    if (!out) return cmr_fail(CMR_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_vertices <= 0 || n_vertices >= (1ll << 31) || n_edges < 0 || (n_edges > 0 && (!src || !dst))) return cmr_fail(CMR_ERR_INVALID, "bad graph arguments");
+    PPR_TRY(hipSetDevice(device_id));
+    // symmetric CSR on the host: every undirected edge (u, v) contributes v to u's row and u to v's row (a self-loop once,
+    // with its weight counted once in the strength), rows in ascending neighbour order so the sums have one fixed order
+    std::vector<double> strength((size_t)n_vertices, 0.0);
+    std::vector<long long> deg((size_t)n_vertices + 1, 0);
+    for (int64_t e = 0; e < n_edges; ++e) {
+        const int u = src[e], v = dst[e];
+        if (u < 0 || v < 0 || u >= n_vertices || v >= n_vertices) return cmr_fail(CMR_ERR_INVALID, "edge %lld has a vertex outside [0, %lld)", (long long)e, (long long)n_vertices);
+        const double w = weight ? weight[e] : 1.0;
+        if (!(w >= 0.0)) return cmr_fail(CMR_ERR_INVALID, "edge %lld has a negative or NaN weight", (long long)e);
+        strength[u] += w; deg[u + 1]++;
+        if (u != v) { strength[v] += w; deg[v + 1]++; }
+    }
+    for (int64_t i = 0; i < n_vertices; ++i) deg[i + 1] += deg[i];
+    const long long ne = deg[n_vertices];
+    std::vector<std::pair<int, double>> ent((size_t)ne);
+    std::vector<long long> fill(deg.begin(), deg.end() - 1);
+    for (int64_t e = 0; e < n_edges; ++e) {
+        const int u = src[e], v = dst[e];
+        const double w = weight ? weight[e] : 1.0;
+        ent[fill[u]++] = {v, w};
+        if (u != v) ent[fill[v]++] = {u, w};
+    }
+    std::vector<int> col((size_t)ne);
+    std::vector<double> wn((size_t)ne);
+    std::vector<int> dang;
+    for (int64_t i = 0; i < n_vertices; ++i) {
+        std::stable_sort(ent.begin() + deg[i], ent.begin() + deg[i + 1], [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+        if (!(strength[i] > 0.0)) dang.push_back((int)i);
+        for (long long e = deg[i]; e < deg[i + 1]; ++e) {
+            const int j = ent[e].first;
+            col[e] = j;
+            wn[e] = strength[j] > 0.0 ? ent[e].second / strength[j] : 0.0;      // mass leaving j along this edge
+        }
+    }
+    cmr_graph* g = new cmr_graph();
+    g->device = device_id; g->nv = n_vertices; g->ne = ne; g->n_dangling = (long long)dang.size();
+    auto up = [&](void** p, const void* h, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 8));
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(*p, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    hipError_t e = up((void**)&g->rowptr, deg.data(), (size_t)(n_vertices + 1) * 8);
+    if (e == hipSuccess) e = up((void**)&g->col, col.data(), (size_t)ne * 4);
+    if (e == hipSuccess) e = up((void**)&g->wnorm, wn.data(), (size_t)ne * 8);
+    if (e == hipSuccess) e = up((void**)&g->dangling, dang.data(), dang.size() * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->reset, (size_t)n_vertices * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->x, (size_t)n_vertices * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->y, (size_t)n_vertices * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->red, (PPR_RED_BLOCKS + 8) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->mm, PPR_RED_BLOCKS * sizeof(float2));
+    if (e != hipSuccess) { cmr_graph_destroy(g); return cmr_fail(e == hipErrorOutOfMemory ? CMR_ERR_OOM : CMR_ERR_HIP, "graph upload: %s", hipGetErrorString(e)); }
+    *out = g;
+    return CMR_OK;
+}
+
+int32_t cmr_graph_destroy(cmr_graph_t* g) {
+    if (!g) return CMR_OK;
+    (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : {(void*)g->rowptr, (void*)g->col, (void*)g->wnorm, (void*)g->dangling, (void*)g->vertex_of_row, (void*)g->reset, (void*)g->x, (void*)g->y,
+                    (void*)g->red, (void*)g->out, (void*)g->seed_v, (void*)g->seed_w, (void*)g->mm})
+        if (p) (void)hipFree(p);
+    delete g;
+    return CMR_OK;
+}
+
+int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_row, int64_t n_rows) {
+    if (!g || (n_rows > 0 && !vertex_of_row) || n_rows < 0) return cmr_fail(CMR_ERR_INVALID, "bad argument");
+    for (int64_t i = 0; i < n_rows; ++i)
+        if (vertex_of_row[i] < 0 || vertex_of_row[i] >= g->nv) return cmr_fail(CMR_ERR_INVALID, "row %lld maps to vertex %d outside the graph", (long long)i, vertex_of_row[i]);
+    PPR_TRY(hipSetDevice(g->device));
+    PPR_TRY(hipDeviceSynchronize());
+    if (g->vertex_of_row) PPR_TRY(hipFree(g->vertex_of_row));
+    if (g->out) PPR_TRY(hipFree(g->out));
+    g->vertex_of_row = nullptr; g->out = nullptr; g->n_rows = 0;
+    PPR_TRY(hipMalloc((void**)&g->vertex_of_row, std::max<size_t>((size_t)n_rows * 4, 8)));
+    PPR_TRY(hipMalloc((void**)&g->out, std::max<size_t>((size_t)n_rows * 8, 8)));
+    if (n_rows) PPR_TRY(hipMemcpy(g->vertex_of_row, vertex_of_row, (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    g->n_rows = n_rows;
+    return CMR_OK;
+}
+
+int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, double tol, int32_t max_iter, double* out_scores, int32_t* iters) {
+    if (!g || !reset || !out_scores) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
+    PPR_TRY(hipSetDevice(g->device));
+    PPR_TRY(hipMemcpyAsync(g->reset, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, nullptr));
+    int rc = ppr_iterate(g, damping, tol, max_iter, nullptr, iters);
+    if (rc) return rc;
+    PPR_TRY(hipMemcpy(out_scores, g->x, (size_t)g->nv * 8, hipMemcpyDeviceToHost));
+    return CMR_OK;
+}
+
+int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, const int32_t* seed_vertices, const double* seed_weights, int32_t n_seeds,
+                      double passage_node_weight, double damping, double tol, int32_t max_iter, double* out_doc_scores, int32_t* iters) {
+    if (!idx || !g || !q_f32 || !out_doc_scores || (n_seeds > 0 && (!seed_vertices || !seed_weights)) || n_seeds < 0)
+        return cmr_fail(CMR_ERR_INVALID, "bad argument");
+    if (!g->vertex_of_row) return cmr_fail(CMR_ERR_INVALID, "cmr_graph_set_passage_vertices was not called");
+    for (int i = 0; i < n_seeds; ++i)
+        if (seed_vertices[i] < 0 || seed_vertices[i] >= g->nv) return cmr_fail(CMR_ERR_INVALID, "seed vertex %d outside the graph", seed_vertices[i]);
+    float* scores = nullptr;
+    long long n = 0;
+    void* st = nullptr;
+    int rc = cmr_index_scores_to_device(idx, q_f32, &scores, &n, &st);       // scan; the scores stay in HBM (index lock held until release)
+    if (rc) return rc;
+    struct Rel { cmr_index_t* i; bool armed = true; ~Rel() { if (armed) (void)cmr_index_scores_release(i); } } rel{idx};
+    if (n != g->n_rows) return cmr_fail(CMR_ERR_INVALID, "index has %lld rows, the passage-vertex map %lld", n, g->n_rows);
+    hipStream_t s = (hipStream_t)st;
+    rc = ensure_seeds(g, std::max(n_seeds, 1));
+    if (rc) return rc;
+    if (n_seeds) {
+        PPR_TRY(hipMemcpyAsync(g->seed_v, seed_vertices, (size_t)n_seeds * 4, hipMemcpyHostToDevice, s));
+        PPR_TRY(hipMemcpyAsync(g->seed_w, seed_weights, (size_t)n_seeds * 8, hipMemcpyHostToDevice, s));
+    }
+    PPR_TRY(hipMemsetAsync(g->reset, 0, (size_t)g->nv * 8, s));
+    const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(n));
+    float2* part = g->mm;
+    if (n) {
+        hipLaunchKernelGGL(ppr_minmax_partial_kernel, dim3(nparts), dim3(PPR_T), 0, s, scores, n, part);
+        hipLaunchKernelGGL(ppr_scatter_kernel, dim3(blocks_for(n)), dim3(PPR_T), 0, s, scores, n, part, nparts, g->vertex_of_row, passage_node_weight, g->reset);
+    }
+    if (n_seeds) hipLaunchKernelGGL(ppr_seed_kernel, dim3(blocks_for(n_seeds)), dim3(PPR_T), 0, s, g->seed_v, g->seed_w, (long long)n_seeds, g->reset);
+    rc = ppr_iterate(g, damping, tol, max_iter, s, iters);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(ppr_gather_kernel, dim3(blocks_for(n)), dim3(PPR_T), 0, s, g->x, g->vertex_of_row, n, g->out);
+    PPR_TRY(hipGetLastError());
+    PPR_TRY(hipMemcpyAsync(out_doc_scores, g->out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    PPR_TRY(hipStreamSynchronize(s));
+    rel.armed = false;
+    return cmr_index_scores_release(idx);          // CMR_ERR_NONFINITE if the query held NaN / Inf
+}
+
+}  // extern "C"

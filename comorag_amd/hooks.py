@@ -9,7 +9,9 @@ scope), exactly the numeric call sites of SURVEY.md §8a:
     retrieve_knn                utils/embed_utils.py:8-97     (name in the ComoRAG module)
     get_similar_summaries       utils/embed_utils.py:109-161  (name in the ComoRAG module)
     MemoryPool.retrieve_similar_nodes  utils/memory_utils.py:188-235 (instance-level, optional)
-Everything else (LLM calls, graph, PPR, clustering) keeps running the reference's code.
+    run_ppr                     ComoRAG.py:1086-1105         → power iteration on a CSR copy of the graph in HBM (no igraph call)
+    graph_search_with_fact_entities  :992-1053               → its passage loop + run_ppr fused on the device (cmr_index_ppr)
+Everything else (LLM calls, graph construction, clustering) keeps running the reference's code.
 """
 from __future__ import annotations
 
@@ -51,16 +53,32 @@ def _matrix_index(mat, dtype: str, device: int) -> Optional[DenseIndex]:
     return idx
 
 
-def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True, index_factory=None):
+def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True, index_factory=None,
+            graph_factory=None, ppr_on_device: bool = True):
     """`index_factory(matrix, dtype, device) -> index` builds the HBM mirror of a host matrix (default: a `DenseIndex`
     filled with `append`); anything with DenseIndex's `scores` / `search` / `sorted_scores` / `__len__` serves — the
-    CPU-tier binding tests pass a numpy stand-in there to exercise this glue on the real reference classes without a GPU."""
+    CPU-tier binding tests pass a numpy stand-in there to exercise this glue on the real reference classes without a GPU.
+    `graph_factory(igraph_like, device) -> graph` likewise (default `comorag_amd.ppr.DeviceGraph.from_igraph`); it must offer
+    `set_passage_vertices(idxs)` and `ppr(reset, damping)`; the fused path additionally goes through
+    `comorag_amd.ppr.ppr_passage_scores` unless the graph object brings its own `passage_scores(index, q, phrase_w, pnw, damping)`."""
     cfg = getattr(rag, "global_config", None)
     dtype = index_dtype or getattr(cfg, "index_dtype", None) or "f32"
     make_index = index_factory or _matrix_index
     lock = threading.Lock()
     orig_prepare = rag.prepare_retrieval_objects
-    rag._hip = {"passage": None, "summary": None, "fact": None, "dtype": dtype}
+    rag._hip = {"passage": None, "summary": None, "fact": None, "graph": None, "dtype": dtype}
+
+    def _make_graph(self):
+        g = getattr(self, "graph", None)
+        if not ppr_on_device or g is None or not hasattr(g, "get_edgelist"):
+            return None
+        if graph_factory is not None:
+            dg = graph_factory(g, device)
+        else:
+            from .ppr import DeviceGraph
+            dg = DeviceGraph.from_igraph(g, device=device)
+        dg.set_passage_vertices(self.passage_node_idxs)
+        return dg
 
     def prepare_retrieval_objects(self):
         with lock:                                    # once-only (the reference races here, :467-468)
@@ -71,6 +89,7 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
             self._hip["fact"] = make_index(self.fact_embeddings, dtype, device)
             if getattr(self.global_config, "need_cluster", False) and hasattr(self, "summary_embeddings"):
                 self._hip["summary"] = make_index(self.summary_embeddings, dtype, device)
+            self._hip["graph"] = _make_graph(self)
 
     def _query_vec(self, kind: str, query: str, instruction_key: str):
         vec = self.query_to_embedding[kind].get(query, None)
@@ -96,7 +115,62 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
         idx = self._hip["summary"] if need_cluster else self._hip["passage"]
         return retrieval.dense_passage_retrieval(idx, _query_vec(self, "passage", query, "query_to_passage"))
 
-    for fn in (prepare_retrieval_objects, get_query_embeddings, get_fact_scores, dense_passage_retrieval):
+    orig_run_ppr = getattr(rag, "run_ppr", None)
+    orig_graph_search = getattr(rag, "graph_search_with_fact_entities", None)
+
+    def run_ppr(self, reset_prob, damping: float = 0.5):
+        g = self._hip["graph"]
+        if g is None:
+            return orig_run_ppr(reset_prob, damping)
+        from . import ppr
+        return ppr.run_ppr(g, reset_prob, self.passage_node_idxs, damping)
+
+    def graph_search_with_fact_entities(self, query, link_top_k, query_fact_scores, top_k_facts, top_k_fact_indices, passage_node_weight: float = 0.05):
+        """ComoRAG.py:992-1053.  Phrase weights as the reference computes them (fact score of the facts that mention the
+        phrase, divided by the number of chunks the entity occurs in, top `link_top_k` phrases kept by the reference's own
+        get_top_k_weights); the passage loop + run_ppr run fused on the device.  (The text -> score map the reference also
+        fills for every passage is dropped there after trimming: dead code, not rebuilt.)"""
+        g, index = self._hip["graph"], self._hip["passage"]
+        if g is None or index is None:
+            return orig_graph_search(query, link_top_k, query_fact_scores, top_k_facts, top_k_fact_indices, passage_node_weight)
+        from importlib import import_module
+        mdhash = import_module(type(self).__module__).compute_mdhash_id
+        phrase_weights = np.zeros(len(self.node_name_to_vertex_idx) if not hasattr(g, "n_vertices") else g.n_vertices)
+        seen: dict = {}
+        used_phrases_with_scores = {}
+        for rank, fact in enumerate(top_k_facts):
+            fact_score = query_fact_scores[top_k_fact_indices[rank]] if query_fact_scores.ndim > 0 else query_fact_scores
+            for phrase in (fact[0].lower(), fact[2].lower()):
+                key = mdhash(content=phrase, prefix="entity-")
+                vid = self.node_name_to_vertex_idx.get(key, None)
+                if vid is not None:
+                    w = fact_score
+                    if self.ent_node_to_num_chunk[key] != 0:
+                        w = w / self.ent_node_to_num_chunk[key]
+                    phrase_weights[vid] = w
+                    if phrase_weights[vid] > 0:
+                        used_phrases_with_scores[phrase] = phrase_weights[vid]
+                seen.setdefault(phrase, []).append(fact_score)
+        linking_score_map = {p: float(np.mean(v)) for p, v in seen.items()}
+        if link_top_k:
+            phrase_weights, linking_score_map = self.get_top_k_weights(link_top_k, phrase_weights, linking_score_map)
+        q = _query_vec(self, "passage", query, "query_to_passage")
+        if hasattr(g, "passage_scores"):
+            doc_scores = g.passage_scores(index, q, phrase_weights, passage_node_weight, 0.5)
+        else:
+            from . import ppr
+            doc_scores = ppr.ppr_passage_scores(index, g, q, phrase_weights, passage_node_weight, 0.5)
+        sorted_doc_ids = np.argsort(doc_scores)[::-1]
+        sorted_doc_scores = doc_scores[sorted_doc_ids.tolist()]
+        assert len(sorted_doc_ids) == len(self.passage_node_idxs)
+        return sorted_doc_ids, sorted_doc_scores, used_phrases_with_scores
+
+    fns = [prepare_retrieval_objects, get_query_embeddings, get_fact_scores, dense_passage_retrieval]
+    if ppr_on_device and orig_run_ppr is not None:
+        fns.append(run_ppr)
+    if ppr_on_device and orig_graph_search is not None:
+        fns.append(graph_search_with_fact_entities)
+    for fn in fns:
         setattr(rag, fn.__name__, types.MethodType(fn, rag))
 
     if patch_module_functions:

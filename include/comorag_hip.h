@@ -173,6 +173,31 @@ int32_t cmr_merge_topk_dev(int32_t device_id, const int64_t* ids_dev, const floa
                            int32_t n_shards, int32_t nq, int32_t k, int64_t* out_ids_dev,
                            float* out_scores_dev, void* stream);
 
+/* ---- graph stage: DPR-seeded personalised PageRank --------------------------------------
+ * Replaces the tail of ComoRAG.graph_search_with_fact_entities (ComoRAG.py:1034-1044: every (passage id, normalised
+ * DPR score) pair copied to the host and scattered into `passage_weights`) and ComoRAG.run_ppr (:1086-1105: igraph /
+ * prpack personalised PageRank — undirected, edge attribute 'weight', damping 0.5 — then pagerank[passage_node_idxs]).
+ *   cmr_graph_create           undirected weighted edge list (igraph's get_edgelist() + es['weight']; weight NULL = 1)
+ *                              -> symmetric CSR in HBM.  A vertex without edges jumps according to the reset vector.
+ *   cmr_graph_set_passage_vertices   vertex of every passage ROW of the index (ComoRAG's passage_node_idxs)
+ *   cmr_graph_ppr              run_ppr alone: reset [n_vertices] (negative / NaN -> 0, ComoRAG.py:1090) -> all scores
+ *   cmr_index_ppr              the fused path for one query: scan -> min_max_normalize(scores) * passage_node_weight
+ *                              scattered into the reset vector on the device, + the (few) phrase seeds -> PPR ->
+ *                              out_doc_scores [n_rows] = pagerank[vertex of row]; 8 * n_rows bytes come back instead of
+ *                              the 12 * N of the full ranking.  The caller sorts (np.argsort(doc_scores)[::-1], :1102).
+ * Power iteration in fp64, ceil(log(tol/2)/log(damping)) steps (<= max_iter; *iters = steps taken), fixed summation
+ * order.  prpack solves the same linear system directly to ~1e-10.                                                     */
+typedef struct cmr_graph cmr_graph_t;
+int32_t cmr_graph_create(int32_t device_id, int64_t n_vertices, int64_t n_edges, const int32_t* src, const int32_t* dst,
+                         const double* weight, cmr_graph_t** out);
+int32_t cmr_graph_destroy(cmr_graph_t* g);
+int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_row, int64_t n_rows);
+int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, double tol, int32_t max_iter, double* out_scores,
+                      int32_t* iters);
+int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, const int32_t* seed_vertices,
+                      const double* seed_weights, int32_t n_seeds, double passage_node_weight, double damping, double tol,
+                      int32_t max_iter, double* out_doc_scores, int32_t* iters);
+
 /* ---- row-shard exchange ------------------------------------------------------------------
  * One process per GPU, each with a row shard (cmr_index_set_id_base makes its searches return global ids).  Per query
  * batch every rank packs its [nq, k] candidates into ONE u64 each — the order-preserving score code in the high word,

@@ -190,3 +190,117 @@ def test_config1_cinderella_plumbing(tmp_path, golden_dir, fake_embedder, numpy_
         tid, tsc = retrieval.dense_passage_topk(ix, vec, 5)
         assert tid[0].tolist() == want_ids
         np.testing.assert_allclose(tsc[0], want_sc, atol=2e-6)
+
+
+class _VS:
+    """igraph's vertex sequence as ComoRAG uses it: iteration yields vertices (v["name"], ComoRAG.py:890), vs["name"] the list (:1005)."""
+
+    def __init__(self, names):
+        self._n = names
+
+    def __iter__(self):
+        return iter([{"name": n} for n in self._n])
+
+    def __getitem__(self, k):
+        assert k == "name"
+        return self._n
+
+    def __len__(self):
+        return len(self._n)
+
+
+class _FakeIGraph:
+    """What ComoRAG touches of its igraph.Graph on the PPR path: vs['name'], vcount, get_edgelist, es['weight'], and
+    personalized_pagerank (ComoRAG.py:1092-1099) — the latter answered by the oracle's direct solve."""
+
+    def __init__(self, names, src, dst, w):
+        self._names, self._src, self._dst, self._w = list(names), list(src), list(dst), list(w)
+        self.vs = _VS(self._names)
+        self.es = {"weight": self._w}
+
+    def vcount(self):
+        return len(self._names)
+
+    def get_edgelist(self):
+        return list(zip(self._src, self._dst))
+
+    def personalized_pagerank(self, vertices=None, damping=0.85, directed=True, weights=None, reset=None, implementation="prpack"):
+        from oracle import ppr_np
+        assert directed is False and weights == "weight" and implementation == "prpack"
+        return ppr_np.personalized_pagerank(len(self._names), self._src, self._dst, self._w, reset, damping).tolist()
+
+
+class _NumpyGraph:
+    """numpy stand-in for comorag_amd.ppr.DeviceGraph (conftest.NumpyIndex's sibling): same call surface, oracle arithmetic."""
+
+    def __init__(self, g, device=0):
+        e = g.get_edgelist()
+        self.n_vertices, self._src, self._dst, self._w = g.vcount(), [a for a, _ in e], [b for _, b in e], list(g.es["weight"])
+        self.rows = None
+
+    def set_passage_vertices(self, idxs):
+        self.rows = list(idxs); self.n_rows = len(self.rows)
+
+    def ppr(self, reset, damping=0.5, **kw):
+        from oracle import ppr_np
+        return ppr_np.personalized_pagerank(self.n_vertices, self._src, self._dst, self._w, reset, damping)
+
+    def passage_scores(self, index, q, phrase_w, pnw, damping):          # what cmr_index_ppr fuses on the device
+        from oracle import ppr_np
+        from oracle import retrieval_np as orc
+        s = index.scores(np.asarray(q, np.float32).reshape(1, -1))[0]
+        r = np.asarray(phrase_w, np.float64).copy()
+        r[self.rows] = orc.min_max_normalize(s).astype(np.float64) * pnw
+        return self.ppr(r, damping)[self.rows]
+
+
+def test_device_ppr_hooks_on_a_real_comorag_instance(tmp_path, fake_embedder, numpy_index_cls):
+    """run_ppr and graph_search_with_fact_entities rebound on a real ComoRAG instance (§8 f4's glue): same ranking and
+    scores as the reference's own methods over a graph whose personalized_pagerank the oracle answers."""
+    from oracle.ref_loader import ref_modules
+    m = ref_modules()
+    ComoRAG = m["ComoRAG"].ComoRAG
+    mdhash = m["misc_utils"].compute_mdhash_id
+    from comorag_amd import hooks
+    from comorag_amd.embedding_store import EmbeddingStore
+
+    def factory(mat, dtype, device):
+        mat = np.asarray(mat, np.float32)
+        if mat.ndim != 2 or len(mat) == 0:
+            return None
+        ix = numpy_index_cls(mat.shape[1], dtype, device); ix.append(mat)
+        return ix
+
+    def build(Store, sub):
+        st = _stores(tmp_path / sub, fake_embedder, Store)
+        rag = _bare_rag(ComoRAG, st, fake_embedder)
+        names = st["entity"].get_all_ids() + st["chunk"].get_all_ids()
+        ne, nc = len(st["entity"].get_all_ids()), len(st["chunk"].get_all_ids())
+        rng = np.random.default_rng(5)
+        src = [int(rng.integers(0, ne)) for _ in range(3 * nc)] + [0, 1, 2]
+        dst = [ne + i // 3 for i in range(3 * nc)] + [1, 2, 3]
+        w = rng.uniform(0.5, 2.0, len(src)).tolist()
+        rag.graph = _FakeIGraph(names, src, dst, w)
+        rag.ent_node_to_num_chunk = {k: (i % 3) for i, k in enumerate(st["entity"].get_all_ids())}
+        return rag
+
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    ours = build(EmbeddingStore, "a")
+    ref = build(m["embedding_store"].EmbeddingStore, "b")
+    hooks.install(ours, index_factory=factory, graph_factory=lambda g, device: _NumpyGraph(g, device), patch_module_functions=False)
+    ours.prepare_retrieval_objects(); ref.prepare_retrieval_objects()
+    assert isinstance(ours._hip["graph"], _NumpyGraph) and ours._hip["graph"].rows == ref.passage_node_idxs
+    nv = ref.graph.vcount()
+    reset = np.zeros(nv); reset[[0, 3, nv - 1]] = [1.0, 0.5, 0.25]; reset[2] = -1.0
+    a_ids, a_sc = ours.run_ppr(reset.copy(), damping=0.5)
+    b_ids, b_sc = ref.run_ppr(reset.copy(), damping=0.5)
+    assert a_ids.tolist() == b_ids.tolist()
+    np.testing.assert_allclose(a_sc, b_sc, atol=1e-12)
+    facts = [("Cinderella", "lost", "Slipper"), ("prince", "found", "slipper"), ("stepmother", "hid", "pumpkin")]   # phrases are lower-cased (:1005-1007)
+    for q in ["who lost a slipper?", "what became a coach?"]:
+        fs = ref.get_fact_scores(q)
+        idxs = np.argsort(fs)[-3:][::-1].tolist()                 # rerank_facts (:1073): the link_top_k best facts, all with a positive score
+        want = ref.graph_search_with_fact_entities(q, 3, fs, facts, idxs, passage_node_weight=0.05)
+        got = ours.graph_search_with_fact_entities(q, 3, ours.get_fact_scores(q), facts, idxs, passage_node_weight=0.05)
+        assert got[0].tolist() == want[0].tolist() and got[2] == want[2]
+        np.testing.assert_allclose(got[1], want[1], atol=1e-9)

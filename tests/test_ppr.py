@@ -1,0 +1,181 @@
+"""PPR seeding + personalised PageRank: the oracle against closed forms (CPU tier), the device
+implementation against the oracle (GPU tier)."""
+import numpy as np
+import pytest
+
+from oracle import ppr_np
+from oracle import retrieval_np as orc
+
+
+def _random_graph(n, m, seed, isolated=()):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, m); dst = rng.integers(0, n, m)
+    keep = (src != dst) & ~np.isin(src, isolated) & ~np.isin(dst, isolated)
+    w = rng.uniform(0.1, 2.0, m)
+    return src[keep].astype(np.int32), dst[keep].astype(np.int32), w[keep]
+
+
+def test_oracle_closed_forms():
+    d = 0.5
+    x = ppr_np.personalized_pagerank(2, [0], [1], None, [1.0, 0.0], d)          # x0 = d x1 + (1-d), x1 = d x0
+    np.testing.assert_allclose(x, [1 / (1 + d), d / (1 + d)], atol=1e-14)
+    # star: centre 0, leaves 1..4, seed on the centre: leaves share d * x0 equally; x0 = d * sum(leaves) + (1 - d)
+    x = ppr_np.personalized_pagerank(5, [0, 0, 0, 0], [1, 2, 3, 4], None, [3.0, 0, 0, 0, 0], d)
+    x0 = (1 - d) / (1 - d * d)
+    np.testing.assert_allclose(x, [x0] + [d * x0 / 4] * 4, atol=1e-14)
+    # weights matter: vertex 0 sends 3/4 of its mass to 1 and 1/4 to 2
+    x = ppr_np.personalized_pagerank(3, [0, 0], [1, 2], [3.0, 1.0], [1.0, 0, 0], d)
+    assert abs(x[1] / x[2] - 3.0) < 1e-12 and abs(x.sum() - 1) < 1e-12
+    # an isolated seed keeps its mass (dangling vertices restart from the reset distribution); negatives / NaN are zeroed
+    x = ppr_np.personalized_pagerank(3, [1], [2], None, [2.0, -1.0, float("nan")], d)
+    np.testing.assert_allclose(x, [1.0, 0.0, 0.0], atol=1e-14)
+    # power iteration reaches the same fixed point
+    src, dst, w = _random_graph(40, 150, 1, isolated=(7,))
+    r = np.random.default_rng(2).uniform(0, 1, 40)
+    M, dang = ppr_np.transition_matrix(40, src, dst, w)
+    rn = r / r.sum(); y = rn.copy()
+    for _ in range(60):
+        y = d * (M @ y + y[dang].sum() * rn) + (1 - d) * rn
+    np.testing.assert_allclose(ppr_np.personalized_pagerank(40, src, dst, w, r, d), y, atol=1e-14)
+
+
+def test_oracle_passage_weights_and_run_ppr_shape():
+    ids = np.array([2, 0, 1]); sc = np.array([1.0, 0.5, 0.0], np.float32)
+    pw = ppr_np.passage_weights(ids, sc, [5, 6, 7], 8, 0.05)
+    np.testing.assert_allclose(pw, [0, 0, 0, 0, 0, 0.025, 0.0, 0.05])
+    order, scores = ppr_np.run_ppr(8, [0, 1, 5, 6], [5, 6, 7, 7], None, pw + np.eye(8)[0], [5, 6, 7])
+    assert sorted(order.tolist()) == [0, 1, 2] and np.all(np.diff(scores) <= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,isolated", [(2, 1, ()), (50, 200, (3, 17)), (3000, 20000, (5,)), (100_000, 600_000, ())])
+def test_device_ppr_equals_oracle(n, m, isolated):
+    from comorag_amd.ppr import DeviceGraph, run_ppr
+    src, dst, w = _random_graph(n, m, n, isolated) if n > 2 else (np.array([0], np.int32), np.array([1], np.int32), np.array([1.0]))
+    rng = np.random.default_rng(n + 1)
+    reset = np.where(rng.uniform(0, 1, n) < 0.1, rng.uniform(0, 1, n), 0.0)
+    reset[0] = 1.0
+    if n > 2:
+        reset[1] = -0.5; reset[2] = np.nan
+    g = DeviceGraph(n, src, dst, w)
+    x = g.ppr(reset, damping=0.5)
+    if n <= 3000:
+        want = ppr_np.personalized_pagerank(n, src, dst, w, reset, 0.5)
+    else:                       # dense solve is O(n^3): sparse power iteration in fp64 as the large-size check
+        import scipy.sparse as sp
+        W = sp.coo_matrix((np.concatenate([w, w]), (np.concatenate([src, dst]), np.concatenate([dst, src]))), shape=(n, n)).tocsr()
+        s = np.asarray(W.sum(axis=1)).ravel()
+        r = np.where(np.isnan(reset) | (reset < 0), 0, reset); r = r / r.sum()
+        want = r.copy()
+        inv = np.where(s > 0, 1.0 / np.where(s > 0, s, 1), 0.0)
+        for _ in range(60):
+            want = 0.5 * (W.T @ (want * inv) + want[s == 0].sum() * r) + 0.5 * r
+    np.testing.assert_allclose(x, want, atol=1e-10, rtol=0)
+    assert abs(x.sum() - 1.0) < 1e-9
+    idxs = list(range(0, n, max(1, n // 50)))
+    a_ids, a_sc = run_ppr(g, reset, idxs)
+    b = np.array([want[i] for i in idxs]); order = np.argsort(b)[::-1]
+    np.testing.assert_allclose(a_sc, b[order], atol=1e-10)
+    g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_dpr_seeded_ppr_equals_the_reference_pipeline(dtype):
+    """cmr_index_ppr vs the oracle's restatement of ComoRAG.py:1034-1045 + :1086-1105 fed with the oracle's
+    dense_passage_retrieval: stationary vector within 1e-6 (fp32 score rounding enters through the reset vector),
+    identical top-k passages."""
+    from comorag_amd.index import DenseIndex
+    from comorag_amd.ppr import DeviceGraph, ppr_passage_ranking, ppr_passage_scores
+    n_pass, n_ent, d = 5000, 1500, 128
+    X = orc.synthetic_corpus(n_pass, d, seed=8); Q = orc.synthetic_queries(3, d, seed=9, planted=X)
+    rng = np.random.default_rng(10)
+    nv = n_ent + n_pass                                  # vertices: entities first, then passages (any mapping works)
+    passage_vertex = (n_ent + rng.permutation(n_pass)).astype(np.int32)
+    src = np.concatenate([rng.integers(0, n_ent, 3 * n_pass), rng.integers(0, n_ent, 2000)]).astype(np.int32)      # passage-entity + entity-entity edges
+    dst = np.concatenate([np.repeat(passage_vertex, 3), rng.integers(0, n_ent, 2000)]).astype(np.int32)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    w = rng.uniform(0.5, 1.5, len(src))
+    idx = DenseIndex(d, dtype); idx.append(X)
+    g = DeviceGraph(nv, src, dst, w); g.set_passage_vertices(passage_vertex)
+    rnd = orc.bf16_round if dtype == "bf16" else (lambda a: a)
+    for qi in range(3):
+        phrase = np.zeros(nv); phrase[rng.integers(0, n_ent, 6)] = rng.uniform(0.2, 1.0, 6)
+        got = ppr_passage_scores(idx, g, Q[qi], phrase, passage_node_weight=0.05)
+        ids, sc = orc.dense_passage_retrieval(rnd(X), rnd(Q[qi:qi + 1]))
+        node_w = phrase + ppr_np.passage_weights(ids, sc, passage_vertex, nv, 0.05)
+        pr = ppr_np.personalized_pagerank(nv, src, dst, w, node_w, 0.5) if nv <= 7000 else None
+        want = pr[passage_vertex]
+        np.testing.assert_allclose(got, want, atol=1e-6 * want.max(), rtol=0)
+        a_ids, a_sc = ppr_passage_ranking(idx, g, Q[qi], phrase, 0.05)
+        order = np.argsort(want)[::-1]
+        assert a_ids[:20].tolist() == order[:20].tolist()
+    idx.close(); g.close()
+
+
+@pytest.mark.gpu
+def test_hooks_put_run_ppr_and_graph_search_on_the_device(golden_dir):
+    """hooks.install on a ComoRAG-shaped object that carries a graph: DeviceGraph built from its edge list, run_ppr and
+    graph_search_with_fact_entities answered by the device (CPU-tier twin on the real class: tests/test_binding_reference.py)."""
+    import os, sys, types
+    from comorag_amd import hooks
+    from comorag_amd.ppr import DeviceGraph
+    g = np.load(os.path.join(golden_dir, "dpr_mid.npz"))
+    X, F, Q = g["X"], g["F"], g["Q"]
+    n_ent = 40
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, n_ent, 4 * len(X)).tolist(); dst = (n_ent + np.repeat(np.arange(len(X)), 4)).tolist()
+    w = rng.uniform(0.5, 1.5, len(src)).tolist()
+    names = [f"entity-{i}" for i in range(n_ent)] + [f"chunk-{i}" for i in range(len(X))]
+
+    class G:
+        vs = {"name": names}
+        es = {"weight": w}
+        def vcount(self): return len(names)
+        def get_edgelist(self): return list(zip(src, dst))
+
+    class Enc:
+        def batch_encode(self, text, **kw): return Q[int(text[1:]):int(text[1:]) + 1]
+
+    class Rag:
+        def __init__(self):
+            self.global_config = types.SimpleNamespace(need_cluster=False, index_dtype="f32")
+            self.embedding_model, self.graph, self.ready_to_retrieve = Enc(), G(), False
+            self.node_name_to_vertex_idx = {n: i for i, n in enumerate(names)}
+            self.ent_node_to_num_chunk = {f"entity-{i}": 1 + i % 2 for i in range(n_ent)}
+        def prepare_retrieval_objects(self):
+            self.query_to_embedding = {"triple": {}, "passage": {}}
+            self.passage_embeddings, self.fact_embeddings = X, F
+            self.passage_node_idxs = list(range(n_ent, n_ent + len(X)))
+            self.ready_to_retrieve = True
+        def run_ppr(self, reset_prob, damping=0.5): raise AssertionError("the reference path must not run")
+        def graph_search_with_fact_entities(self, *a, **k): raise AssertionError("the reference path must not run")
+        def get_top_k_weights(self, link_top_k, w_, m_): return w_, m_
+
+    mod = sys.modules[Rag.__module__]
+    mod.get_query_instruction = lambda k: k
+    mod.compute_mdhash_id = lambda content, prefix="": prefix + content
+    rag = hooks.install(Rag(), patch_module_functions=False)
+    rag.prepare_retrieval_objects()
+    assert isinstance(rag._hip["graph"], DeviceGraph)
+    nv = len(names)
+    reset = np.zeros(nv); reset[[1, 5, nv - 3]] = [1.0, 2.0, 0.5]
+    ids, sc = rag.run_ppr(reset)
+    want = ppr_np.personalized_pagerank(nv, src, dst, w, reset, 0.5)[n_ent:]
+    order = np.argsort(want)[::-1]
+    assert ids.tolist() == order.tolist()
+    np.testing.assert_allclose(sc, want[order], atol=1e-10)
+    fs = rag.get_fact_scores("q1")
+    facts = [("1", "rel", "5"), ("7", "rel", "9")]
+    ids2, sc2, used = rag.graph_search_with_fact_entities("q1", 0, fs, facts, [0, 1], passage_node_weight=0.05)
+    pw = np.zeros(nv)
+    for (a, _, b), fi in zip(facts, [0, 1]):
+        for ph in (a, b):
+            pw[int(ph)] = fs[fi] / (1 + int(ph) % 2)
+    d_ids, d_sc = orc.dense_passage_retrieval(X, Q[1:2])
+    node_w = pw + ppr_np.passage_weights(d_ids, d_sc, rag.passage_node_idxs, nv, 0.05)
+    want2 = ppr_np.personalized_pagerank(nv, src, dst, w, node_w, 0.5)[n_ent:]
+    np.testing.assert_allclose(sc2, np.sort(want2)[::-1], atol=2e-7 * want2.max())
+    assert ids2[:10].tolist() == np.argsort(want2)[::-1][:10].tolist() and set(used) <= {"1", "5", "7", "9"}
+    rag._hip["graph"].close()
