@@ -299,7 +299,8 @@ int balanced_grid(long long npanels, int grid, int lists_per_wg) {
 // event orders them, so the pre-phase of the NEXT pass/batch can overlap this pass's main scan.
 int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, hipStream_t sq, hipEvent_t ev_pre, hipEvent_t ev_scan,
                  hipEvent_t ev_lists_free, const float* q_dev, int nqp,
-                 int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false) {
+                 int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false,
+                 const float* min_score = nullptr) {
     CmrScanGeom g;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
     int rc = arm_flag(ws, sp);   // zeroed once; the reader re-arms it after reporting
@@ -318,7 +319,9 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     // Wide kernel: the sampling workgroups split the sampled panels among them (one list per workgroup and query).
     long long level_panels[2] = {0, 0};
     int n_levels = 0;
-    if (!idx->no_sample && npanels >= 256) {
+    // threshold search (min_score): the caller's bound is the initial threshold of every query — already selective, so no
+    // sampling passes
+    if (!idx->no_sample && npanels >= 256 && !min_score) {
         const long long s0 = std::max<long long>(16, k);                       // panels
         level_panels[n_levels++] = s0;
         if (npanels >= 4096) {
@@ -396,6 +399,11 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     CmrScanArgs a{};
     a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
     a.nq = nqp;
+    if (min_score) {
+        // key > tau  <=>  score >= *min_score: tau = (smallest key with that score) - 1
+        HIP_TRY(cmr_launch_fill_threshold(*min_score, NQ, (u64*)ws->tau.p, sp));
+        a.tau_init = (u64*)ws->tau.p;
+    }
     for (int lv = 0; lv < n_levels; ++lv) {
         const long long spn = level_panels[lv];
         CmrScanGeom gs = g;
@@ -449,12 +457,15 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
 }
 
 int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev,
-                   float* min_dev, float* max_dev) {
-    if (k > CMR_MAX_K) return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
+                   float* min_dev, float* max_dev, const float* min_score = nullptr) {
+    if (k > CMR_MAX_K) {
+        if (min_score) return fail(CMR_ERR_UNSUPPORTED, "threshold search supports k <= %d", CMR_MAX_K);
+        return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
+    }
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     {   // tiny corpus: one single-workgroup launch does packing, scan, selection and min/max
         const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-        if (!idx->no_tiny && npanels <= 32 && nq <= 16 && idx->n > 0) {
+        if (!idx->no_tiny && !min_score && npanels <= 32 && nq <= 16 && idx->n > 0) {
             { int rc_ = arm_flag(ws, ws->stream); if (rc_) return rc_; }
             HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels)));
             HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, (float*)ws->d_out.p,
@@ -470,7 +481,7 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         const int nqp = std::min(wide ? wideq : narrow, left);
         int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr, wide);
+                              max_dev ? max_dev + q0 : nullptr, wide, min_score);
         if (rc) return rc;
         q0 += nqp;
     }
@@ -891,8 +902,8 @@ int32_t cmr_event_synchronize(void* event) {
     return CMR_OK;
 }
 
-int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
-                         float* out_min, float* out_max) {
+static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
+                           float* out_min, float* out_max, const float* min_score) {
     if (!idx || !q || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
     if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
     if (k <= 0 || k > CMR_MAX_K_2PASS) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K_2PASS);
@@ -918,7 +929,7 @@ int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k
     memcpy(ws->h_pin, q, q_bytes);
     HIP_TRY(hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s));
     char* pk = (char*)ws->d_pack.p;
-    rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max));
+    rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max), min_score);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     HIP_TRY(hipMemcpyAsync(ws->h_pin, pk, out_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -934,6 +945,17 @@ int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k
     if (out_min) memcpy(out_min, hp + o_min, (size_t)nq * 4);
     if (out_max) memcpy(out_max, hp + o_max, (size_t)nq * 4);
     return CMR_OK;
+}
+
+int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
+                         float* out_min, float* out_max) {
+    return host_search(idx, q, nq, k, out_ids, out_scores, out_min, out_max, nullptr);
+}
+
+int32_t cmr_index_search_min_score(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, float min_score, int64_t* out_ids,
+                                   float* out_scores) {
+    if (!(min_score == min_score)) return fail(CMR_ERR_INVALID, "min_score is NaN");
+    return host_search(idx, q, nq, k, out_ids, out_scores, nullptr, nullptr, &min_score);
 }
 
 int32_t cmr_index_scores_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, float* out_dev, int64_t ld, void* stream) {

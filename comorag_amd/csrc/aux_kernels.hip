@@ -56,6 +56,16 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     if (bad) atomicOr(flag, 1);
 }
 
+// tau[i] = (smallest candidate key whose score is >= min_score) - 1, so that key > tau <=> score >= min_score
+__global__ void fill_threshold_kernel(float min_score, int n, u64* __restrict__ tau) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tau[i] = cmr_make_key(min_score, 0xFFFFFFFFu) - 1ull;
+}
+hipError_t cmr_launch_fill_threshold(float min_score, int n, u64* tau, hipStream_t s) {
+    hipLaunchKernelGGL(fill_threshold_kernel, dim3((n + 255) / 256), dim3(256), 0, s, min_score, n, tau);
+    return hipGetLastError();
+}
+
 hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt, void* qfrag,
                                    int* flag, hipStream_t s) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;

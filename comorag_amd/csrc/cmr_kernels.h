@@ -57,6 +57,8 @@ size_t cmr_wide_lds_bytes(int ks, int cap);
 // queries fp32 [nq, dim] (device) -> fragment-ordered blocks of the index dtype, zero padded
 hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt,
                                    void* qfrag, int* nonfinite_flag, hipStream_t s);
+// threshold search: n initial threshold keys that admit exactly the scores >= min_score
+hipError_t cmr_launch_fill_threshold(float min_score, int n, u64* tau, hipStream_t s);
 // rows fp32 [n, dim] (device) -> panel-major blocks at row offset row0 (+ optional fp32 shadow)
 hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, int dim, int dpad,
                                    long long row0, void* corpus, float* shadow, int* nonfinite_flag,

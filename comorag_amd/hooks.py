@@ -54,7 +54,7 @@ def _matrix_index(mat, dtype: str, device: int) -> Optional[DenseIndex]:
 
 
 def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True, index_factory=None,
-            graph_factory=None, ppr_on_device: bool = True):
+            graph_factory=None, ppr_on_device: bool = True, knn_threshold_filter: bool = True):
     """`index_factory(matrix, dtype, device) -> index` builds the HBM mirror of a host matrix (default: a `DenseIndex`
     filled with `append`); anything with DenseIndex's `scores` / `search` / `sorted_scores` / `__len__` serves — the
     CPU-tier binding tests pass a numpy stand-in there to exercise this glue on the real reference classes without a GPU.
@@ -177,8 +177,11 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
         mod = sys.modules.get(type(rag).__module__)
         if mod is not None:
             def _knn(query_ids, key_ids, query_vecs, key_vecs, k=2047, query_batch_size=1000, key_batch_size=10000):
+                # the module's one caller (add_synonymy_edges, :670-712) stops at synonymy_edge_sim_threshold: hand it to the
+                # kernel as the starting threshold instead of materialising 2047 neighbours per entity
+                thr = getattr(cfg, "synonymy_edge_sim_threshold", None) if knn_threshold_filter else None
                 return retrieval.retrieve_knn(query_ids, key_ids, query_vecs, key_vecs, k=k, query_batch_size=query_batch_size,
-                                              key_batch_size=key_batch_size, index_dtype=dtype, device=device)
+                                              key_batch_size=key_batch_size, index_dtype=dtype, device=device, min_score=thr)
             if hasattr(mod, "retrieve_knn"):
                 mod.retrieve_knn = _knn
             if hasattr(mod, "get_similar_summaries"):

@@ -98,6 +98,17 @@ class DenseIndex:
         kk = min(k, len(self))
         return ids[:, :kk], sc[:, :kk], mn, mx
 
+    def search_min_score(self, q, k: int, min_score: float) -> Tuple[np.ndarray, np.ndarray]:
+        """The k best rows among those with raw score >= min_score: (ids [nq,k], scores [nq,k]), -1 / -inf padded."""
+        q = _f32c(q)
+        if q.ndim == 1:
+            q = q[None, :]
+        nq = q.shape[0]
+        ids = np.empty((nq, k), dtype=np.int64)
+        sc = np.empty((nq, k), dtype=np.float32)
+        L.check(L.lib().cmr_index_search_min_score(self._h, _ptr(q), nq, k, float(min_score), _ptr(ids), _ptr(sc)))
+        return ids, sc
+
     def search_dev(self, q_t, k: int, out_ids=None, out_scores=None, out_min=None, out_max=None,
                    stream: Optional[int] = None):
         """Asynchronous search on torch CUDA tensors, enqueued on torch's current stream (also when that is the default

@@ -103,13 +103,20 @@ def _l2n(x: np.ndarray) -> np.ndarray:
 
 def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, key_vecs, k: int = 2047,
                  query_batch_size: int = 1000, key_batch_size: int = 10000, index_dtype: str = "f32",
-                 device: int = 0) -> Dict[str, Tuple[List[str], List[float]]]:
-    """utils/embed_utils.py:8-97 — fp32 re-normalise both sides, exact top-k of every query over all
-    keys, `{query_id: ([key ids], [scores])}`.  The reference's key-block loop + merge computes the
-    global top-k, so one pass over a single HBM index gives the same answer; k <= 128 uses the fused
-    scan+top-k kernel, larger k (synonymy_edge_topk = 2047, up to 4096) materialises the score block in
-    HBM and selects per row on the device; only k > 4096 falls back to a host select of GPU scores.  Equal scores: lower key index first (torch.topk's tie
-    order is unspecified)."""
+                 device: int = 0, min_score: Optional[float] = None, max_neighbours: int = 128) -> Dict[str, Tuple[List[str], List[float]]]:
+    """utils/embed_utils.py:8-97 — fp32 re-normalise both sides, exact top-k of every query over all keys,
+    `{query_id: ([key ids], [scores])}`.  The reference's key-block loop + merge computes the global top-k, so one pass
+    over a single HBM index gives the same answer; k <= 128 uses the fused scan+top-k kernel, larger k
+    (synonymy_edge_topk = 2047, up to 4096) materialises the score block in HBM and selects per row on the device; only
+    k > 4096 falls back to a host select of GPU scores.  Equal scores: lower key index first (torch.topk's tie order is
+    unspecified).
+
+    `min_score` (not in the reference signature): the caller will stop at the first neighbour below this score — as the
+    only caller does, ComoRAG.add_synonymy_edges (:696-699: `score < synonymy_edge_sim_threshold or num_nns > 100`).  Then
+    each list holds the neighbours with score >= min_score only, best first, found by the fused kernel with its threshold
+    started at min_score (cmr_index_search_min_score) — no [nq, N] score block, no 2047-wide selection.  A query with
+    more than `max_neighbours` (<= 128) such neighbours is re-run through the exact large-k path, so every list is a
+    prefix-complete answer: what the consumer reads is identical."""
     if len(key_vecs) == 0:
         return {}
     q = _l2n(np.asarray(query_vecs, dtype=np.float32))
@@ -119,9 +126,24 @@ def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, k
         index.append(kx)
         kk = min(k, len(kx))
         results: Dict[str, Tuple[List[str], List[float]]] = {}
-        from ._lib import CMR_MAX_K_2PASS
+        from ._lib import CMR_MAX_K, CMR_MAX_K_2PASS
+        thr_k = min(max_neighbours, CMR_MAX_K, kk)
         for s in range(0, len(q), query_batch_size):
             qb = q[s:s + query_batch_size]
+            if min_score is not None and kk > thr_k:
+                ids, sc = index.search_min_score(qb, thr_k, min_score)
+                full = np.flatnonzero(ids[:, -1] >= 0)                  # lists that filled up: more neighbours may exist
+                redo = dict(zip(full.tolist(), zip(*index.search(qb[full], kk, with_minmax=False)[:2]))) if len(full) and kk <= CMR_MAX_K_2PASS else {}
+                for r in range(len(qb)):
+                    if r in redo:
+                        ri, rs = redo[r]
+                        keep = rs >= np.float32(min_score)
+                        ri, rs = ri[keep], rs[keep]
+                    else:
+                        keep = ids[r] >= 0
+                        ri, rs = ids[r][keep], sc[r][keep]
+                    results[query_ids[s + r]] = ([key_ids[j] for j in ri], rs.tolist())
+                continue
             if kk <= CMR_MAX_K_2PASS:      # fused kernel (k <= 128) or device scores + per-row select
                 ids, sc, _, _ = index.search(qb, kk, with_minmax=False)
             else:

@@ -104,6 +104,13 @@ int32_t cmr_index_append_dev(cmr_index_t* idx, const float* rows_f32_dev, int64_
  *   out_min/out_max [nq] fp32 over ALL rows (NULL allowed)                                     */
 int32_t cmr_index_search(cmr_index_t* idx, const float* q_f32, int32_t nq, int32_t k,
                          int64_t* out_ids, float* out_scores, float* out_min, float* out_max);
+/* Threshold search: the k best rows among those with raw score >= min_score (-1 / -inf padded) — the fused kernel's
+ * running threshold simply starts at min_score, so nothing below it is ever pushed, merged or written.  This is what
+ * the synonymy self-join consumes: ComoRAG.add_synonymy_edges (ComoRAG.py:670-712) asks retrieve_knn for 2047 neighbours
+ * of every entity and then stops at the first score < synonymy_edge_sim_threshold (0.8) or after 101 accepted ones
+ * (:696-699), i.e. it reads ~1/20 of what the reference materialises.  k <= CMR_MAX_K.                                  */
+int32_t cmr_index_search_min_score(cmr_index_t* idx, const float* q_f32, int32_t nq, int32_t k, float min_score,
+                                   int64_t* out_ids, float* out_scores);
 int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
                              int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
                              float* out_max_dev, void* stream);

@@ -133,6 +133,43 @@ def test_retrieve_knn_vs_reference_and_large_k(golden_dir):
     assert retrieval.retrieve_knn([], [], np.zeros((0, 4)), np.zeros((0, 4))) == {}
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_retrieve_knn_threshold_filter_feeds_the_synonymy_consumer_identically(dtype):
+    """retrieve_knn(min_score=0.8) — fused kernel started at the threshold — vs the oracle's retrieve_knn
+    (k = 2047) cut where ComoRAG.add_synonymy_edges stops reading (:696-699).  Entities with near-duplicates, one with
+    more than 128 of them (forces the exact re-run), and one with none."""
+    from comorag_amd import retrieval
+    rng = np.random.default_rng(12)
+    base = orc.synthetic_corpus(3000, 768, seed=12)
+    E = [base]
+    for j, copies in enumerate([3, 1, 150, 20]):                 # clusters of near-duplicates around base[j]
+        E.append(base[j] + 0.02 * rng.standard_normal((copies, 768)).astype(np.float32) / np.sqrt(768) * np.sqrt(768) * 0.1)
+    E = np.concatenate(E).astype(np.float32)
+    ids = [f"e{i}" for i in range(len(E))]
+    rnd = orc.bf16_round if dtype == "bf16" else (lambda a: a)
+    got = retrieval.retrieve_knn(ids, ids, E, E, k=2047, query_batch_size=512, index_dtype=dtype, min_score=0.8)
+    En = rnd(orc._l2n(E))
+    exact = orc.exact_scores_f64(En, En)
+    n_full = 0
+    for i, qid in enumerate(ids):
+        want = np.flatnonzero(exact[i] >= 0.8 - 4e-6)
+        order = want[np.lexsort((want, -exact[i][want]))]
+        gi = np.array([int(x[1:]) for x in got[qid][0]], dtype=np.int64)
+        sure = order[exact[i][order] >= 0.8 + 4e-6]               # rows within fp32 rounding of the threshold may go either way
+        assert set(sure.tolist()) <= set(gi.tolist()) <= set(order.tolist()), qid
+        assert np.all(np.diff(got[qid][1]) <= 0) and (len(gi) == 0 or got[qid][1][-1] >= 0.8 - 4e-6)
+        np.testing.assert_allclose(got[qid][1], exact[i][gi], atol=4e-6)
+        n_full += len(gi) > 128
+    assert n_full >= 150 and len(got["e2999"][0]) == 1               # the big cluster took the exact path; a lone entity finds itself
+    # what the consumer reads (self excluded, <= 101 neighbours) is the reference's
+    ref = orc.retrieve_knn(ids[:40] + ids[3004:3010], ids, E[list(range(40)) + list(range(3004, 3010))], E, k=2047) if dtype == "f32" else None
+    if ref is not None:
+        for qid in ref:
+            cut = [(n, s) for n, s in zip(*ref[qid]) if s >= 0.8][:103]
+            mine = list(zip(*got[qid]))[:len(cut)]
+            assert [n for n, _ in mine] == [n for n, _ in cut] or all(abs(a[1] - b[1]) < 4e-6 for a, b in zip(mine, cut))
+
+
 def test_memory_pool_numeric(golden_dir, fake_embedder):
     from comorag_amd import retrieval
     from comorag_amd.index import DenseIndex
