@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round-2 profile collection on the GPU box (gpurun): kernel trace of bench.py, PMC traffic passes of the headline
+# configuration, SQ counters of the wide kernel.  Summaries land in gpurun_out/r2_profiles/ (copied to profiles/ by hand).
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r2_profiles; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $O/kt -o w -- python $R/bench.py --no-cpu-baseline > $O/bench_under_trace.json 2> $O/kt.err
+python $R/tools/rocpd_stats.py $O/kt/w_results.db > $O/r2_bench_kernel_stats.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o w -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2> $O/pmc_$c.err
+  python $R/tools/rocpd_pmc.py $O/pmc_$c/w_results.db scan_kernel 1000 > $O/pmc_$c.jsonl
+done
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --kernel-trace -d $O/pmc_wide_a -o w -- python $R/tools/pipe_only.py 10000000 256 12 > /dev/null 2> $O/pmc_wide_a.err
+python $R/tools/rocpd_pmc.py $O/pmc_wide_a/w_results.db scan_wide 1000 > $O/pmc_wide_a.jsonl
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM --kernel-trace -d $O/pmc_wide_b -o w -- python $R/tools/pipe_only.py 10000000 256 12 > /dev/null 2> $O/pmc_wide_b.err
+python $R/tools/rocpd_pmc.py $O/pmc_wide_b/w_results.db scan_wide 1000 > $O/pmc_wide_b.jsonl
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_wide_$c -o w -- python $R/tools/pipe_only.py 10000000 256 12 > /dev/null 2> $O/pmc_wide_$c.err
+  python $R/tools/rocpd_pmc.py $O/pmc_wide_$c/w_results.db scan_wide 1000 > $O/pmc_wide_$c.jsonl
+done
+rm -rf $O/*/w_results.db.tmp; du -sh $O; ls $O
