@@ -257,36 +257,33 @@ class EmbeddingStore:
             self._save_data()
 
     # ------------------------------------------------------------------ reference API
-    def get_missing_string_hash_ids(self, texts: List[str]):
-        nodes_dict = {}
+    def _plan(self, texts: List[str]):
+        """Ids and texts that are new to the store, in first-occurrence order.  A dict keyed by md5 id collapses repeated
+        texts exactly as the reference's `nodes_dict` does: the first occurrence fixes the position, a later duplicate
+        only rewrites the (identical) content (embedding_store.py:47-50 / :66-69)."""
+        by_id: Dict[str, str] = {}
         for text in texts:
-            nodes_dict[compute_mdhash_id(text, prefix=self.namespace + "-")] = {"content": text}
-        all_hash_ids = list(nodes_dict.keys())
-        if not all_hash_ids:
-            return {}
-        existing = self.hash_id_to_row.keys()
-        missing_ids = [h for h in all_hash_ids if h not in existing]
-        texts_to_encode = [nodes_dict[h]["content"] for h in missing_ids]
-        return {h: {"hash_id": h, "content": t} for h, t in zip(missing_ids, texts_to_encode)}
+            by_id[compute_mdhash_id(text, prefix=self.namespace + "-")] = text
+        known = self.hash_id_to_row
+        fresh = [(h, t) for h, t in by_id.items() if h not in known]
+        return len(by_id), [h for h, _ in fresh], [t for _, t in fresh]
+
+    def get_missing_string_hash_ids(self, texts: List[str]):
+        """embedding_store.py:44-61: {hash_id: {"hash_id", "content"}} of the texts not stored yet ({} for no input)."""
+        _, ids, new_texts = self._plan(texts)
+        return {h: {"hash_id": h, "content": t} for h, t in zip(ids, new_texts)}
 
     def insert_strings(self, texts: List[str]):
-        """embedding_store.py:63-90: dict-dedup (first occurrence keeps its slot), skip known ids,
-        ONE batch_encode call for the missing texts, upsert.  Returns None / {} like the reference."""
+        """embedding_store.py:63-90: skip known ids, ONE batch_encode call for the new texts, upsert.  Returns None for
+        empty input or after inserting, {} when everything was known — as the reference does."""
         with self._lock:
-            nodes_dict = {}
-            for text in texts:
-                nodes_dict[compute_mdhash_id(text, prefix=self.namespace + "-")] = {"content": text}
-            all_hash_ids = list(nodes_dict.keys())
-            if not all_hash_ids:
+            n_seen, ids, new_texts = self._plan(texts)
+            if n_seen == 0:
                 return
-            existing = self.hash_id_to_row.keys()
-            missing_ids = [h for h in all_hash_ids if h not in existing]
-            logger.info(f"Inserting {len(missing_ids)} new records, {len(all_hash_ids) - len(missing_ids)} records already exist.")
-            if not missing_ids:
+            logger.info(f"Inserting {len(ids)} new records, {n_seen - len(ids)} records already exist.")
+            if not ids:
                 return {}
-            texts_to_encode = [nodes_dict[h]["content"] for h in missing_ids]
-            missing_embeddings = self.embedding_model.batch_encode(texts_to_encode)
-            self._upsert(missing_ids, texts_to_encode, missing_embeddings)
+            self._upsert(ids, new_texts, self.embedding_model.batch_encode(new_texts))
 
     def get_row(self, hash_id):
         return self.hash_id_to_row[hash_id]

@@ -431,6 +431,66 @@ def test_threads_concurrent_search():
     idx.close()
 
 
+def test_concurrent_append_and_search():
+    """Writers and readers on one index (cmr_index's shared_mutex: searches shared, append exclusive — ComoRAG's 16
+    question threads search while insert_strings appends).  Appends force several capacity doublings while
+    8 threads search; every answer must be the exact top-k of SOME prefix of the rows (the index is never seen
+    half-appended), planted rows that exist from the start always come first, and the end state equals a bulk build."""
+    import threading
+    from comorag_amd.index import DenseIndex
+    d, k = 128, 10
+    X = orc.synthetic_corpus(60_000, d, seed=71)
+    Q = orc.synthetic_queries(6, d, seed=72)
+    Q[0] = X[5]; Q[1] = X[777]                                    # present from the first chunk on
+    Xr, Qr = orc.bf16_round(X), orc.bf16_round(Q)
+    exact = Qr.astype(np.float64) @ Xr.astype(np.float64).T
+    chunks = [(0, 2000)] + [(a, min(a + 3500, len(X))) for a in range(2000, len(X), 3500)]
+    bounds = [b for _, b in chunks]
+    idx = DenseIndex(d, "bf16", capacity_hint=16)                 # tiny hint: the matrix is reallocated again and again
+    idx.append(X[:2000])
+    stop, errors, seen = threading.Event(), [], []
+
+    def reader(t):
+        try:
+            while not stop.is_set():
+                n0 = len(idx)
+                ids, sc, mn, mx = idx.search(Q, k)
+                n1 = len(idx)
+                ok = False
+                for n in [b for b in bounds if n0 <= b <= n1]:   # the state searched is one of the committed prefixes
+                    ref_ids, _ = orc.topk_rule(exact[:, :n], k)
+                    try:
+                        for i in range(len(Q)):
+                            orc.assert_topk_equivalent(ids[i], ref_ids[i], exact[i], ERR)
+                        ok = True
+                        break
+                    except AssertionError:
+                        continue
+                if not ok:
+                    errors.append((t, n0, n1, ids[:, :3].tolist()))
+                if ids[0, 0] != 5 or ids[1, 0] != 777:
+                    errors.append((t, "planted", ids[:2, 0].tolist()))
+                seen.append(n1)
+        except Exception as e:              # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=reader, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for a, b in chunks[1:]:
+        idx.append(X[a:b])
+    stop.set()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert len(idx) == len(X) and len(set(seen)) >= 3            # the readers really overlapped the appends
+    ids, sc, _, _ = idx.search(Q, k)
+    bulk = DenseIndex(d, "bf16"); bulk.append(X)
+    bi, bs, _, _ = bulk.search(Q, k)
+    assert np.array_equal(ids, bi) and np.array_equal(sc, bs)
+    idx.close(); bulk.close()
+
+
 def test_c2_size_properties():
     """BASELINE config 2 size: 1M x 768 bf16, B=64, k=20 — oracle on the full size (numpy fp32 BLAS,
     fp64 arbitration on disagreements) + planted rows + shard-merge equivalence."""
