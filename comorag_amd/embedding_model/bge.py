@@ -10,7 +10,9 @@ the reference:
   * `encode(list)` positional returns a torch tensor [n, D] (memory_utils.py:176,205,297 index it).
 Fixed consciously: `max_length` is clamped to the model's `max_position_embeddings` (the reference
 default 2048 overflows BERT's 512 positions), `embedding_model_dtype` is honoured, and
-tokenisation of the next mini-batches (a pool of host threads) overlaps the forward of mini-batch i.
+tokenisation of the next mini-batches (a pool of host threads) overlaps the forward of mini-batch i; with more than
+one mini-batch the prompts are grouped by token count (`embedding_length_bucketing`, default on): a row's embedding
+does not depend on its neighbours in the mini-batch beyond GEMM rounding, and short chunks stop paying for long ones.
 """
 from __future__ import annotations
 
@@ -37,6 +39,28 @@ def tokenize_batch(tokenizer, prompts: List[str], max_length: int):
     import torch
     enc = tokenizer(prompts, padding=True, truncation=True, max_length=int(max_length), return_tensors=None)
     return {k: torch.from_numpy(np.asarray(v, dtype=np.int64)) for k, v in enc.items()}
+
+
+def tokenize_ragged(tokenizer, prompts: List[str], max_length: int):
+    """Token ids per prompt, truncated, NOT padded (for length-bucketed mini-batches)."""
+    enc = tokenizer(prompts, padding=False, truncation=True, max_length=int(max_length), return_tensors=None)
+    return enc["input_ids"]
+
+
+def pad_batch(tokenizer, id_lists):
+    """The tensors `tokenizer(..., padding=True, return_tensors="pt")` would build for these id lists (BERT-style
+    inputs: input_ids right-padded with pad_token_id, attention_mask, token_type_ids all zero for single segments)."""
+    import torch
+    n, width = len(id_lists), max(len(x) for x in id_lists)
+    ids = np.full((n, width), tokenizer.pad_token_id or 0, dtype=np.int64)
+    mask = np.zeros((n, width), dtype=np.int64)
+    for r, x in enumerate(id_lists):
+        ids[r, :len(x)] = x
+        mask[r, :len(x)] = 1
+    out = {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}
+    if "token_type_ids" in getattr(tokenizer, "model_input_names", ()):
+        out["token_type_ids"] = torch.zeros((n, width), dtype=torch.int64)
+    return out
 
 
 def pool_l2norm(hidden, mask, normalize: bool = True):
@@ -83,9 +107,13 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self.embedding_dim = self.embedding_model.config.hidden_size
         self.max_positions = int(getattr(self.embedding_model.config, "max_position_embeddings", 1 << 30))
         import os
+        # mini-batches of similar token count (sorted by length, results scattered back): a mini-batch is padded to ITS
+        # longest prompt, so mixing a 40-token and a 512-token chunk wastes 92 % of the short one's forward
+        self._bucket = bool(cfg_get(self.global_config, "embedding_length_bucketing", True))
         self._tok_workers = max(1, min(int(cfg_get(self.global_config, "embedding_tokenizer_threads", 2)), os.cpu_count() or 1))
         self._tok_pool = ThreadPoolExecutor(max_workers=self._tok_workers, thread_name_prefix="cmr-tok")
-        if cfg_get(self.global_config, "embedding_cache_enabled", False):
+        self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
+        if self._cached:
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
             self.encode = make_cache_embed(self._encode, path, self.device)
         else:
@@ -137,7 +165,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         else:
             params["instruction"] = params.get("passage_instruction", BGE_PREFIX)
         batch_size = params.pop("batch_size", 16)
-        if len(texts) <= batch_size or self.encode is not self._encode:
+        if len(texts) <= batch_size or self._cached:      # (not `self.encode is not self._encode`: bound methods are never identical)
             if len(texts) <= batch_size:
                 params["prompts"] = texts
                 results = self.encode(**params)
@@ -155,17 +183,46 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             max_length = params.get("max_length", 512)
             normalize = params.get("normalize", True)
             chunks = [texts[i:i + batch_size] for i in range(0, len(texts), batch_size)]
-            prep = lambda c: self._tokenize([instr + t for t in c] if instr else list(c), max_length)
             ahead = self._tok_workers + 1
-            futs = [self._tok_pool.submit(prep, c) for c in chunks[:ahead]]
-            parts = []
-            for i in range(len(chunks)):
-                inputs = futs[i].result()
-                futs[i] = None
-                if i + ahead < len(chunks):
-                    futs.append(self._tok_pool.submit(prep, chunks[i + ahead]))
-                parts.append(self._forward_pool(inputs, normalize))
-            results = torch.cat(parts, dim=0)
+            if self._bucket:
+                # 1. token ids of everything (worker threads, reference chunks), 2. stable sort by token count,
+                # 3. mini-batches of `batch_size` neighbours, each padded to its own longest, 4. scatter back
+                ml = min(int(max_length), self.max_positions)
+                rag = lambda c: tokenize_ragged(self.tokenizer, [instr + t for t in c] if instr else list(c), ml)
+                id_lists = [x for part in self._tok_pool.map(rag, chunks) for x in part]
+                lens = np.array([len(x) for x in id_lists])
+                order = np.argsort(lens, kind="stable")
+                # a mini-batch holds as many rows as fit the token budget of a full-length one (batch_size x ml padded
+                # tokens; at most 8 x batch_size rows): at bf16 a 32-row forward of short chunks is launch-bound
+                budget, groups, start = batch_size * ml, [], 0
+                while start < len(order):
+                    end = start + 1
+                    while end < len(order) and end - start < 8 * batch_size and (end - start + 1) * lens[order[end]] <= budget:
+                        end += 1
+                    groups.append(order[start:end])
+                    start = end
+                prep = lambda g: pad_batch(self.tokenizer, [id_lists[j] for j in g])
+                futs = [self._tok_pool.submit(prep, g) for g in groups[:ahead]]
+                parts = []
+                for i in range(len(groups)):
+                    inputs = futs[i].result()
+                    futs[i] = None
+                    if i + ahead < len(groups):
+                        futs.append(self._tok_pool.submit(prep, groups[i + ahead]))
+                    parts.append(self._forward_pool(inputs, normalize))
+                results = torch.empty((len(texts), parts[0].shape[1]), dtype=parts[0].dtype, device=parts[0].device)
+                results[torch.from_numpy(np.concatenate(groups)).to(results.device)] = torch.cat(parts, dim=0)
+            else:
+                prep = lambda c: self._tokenize([instr + t for t in c] if instr else list(c), max_length)
+                futs = [self._tok_pool.submit(prep, c) for c in chunks[:ahead]]
+                parts = []
+                for i in range(len(chunks)):
+                    inputs = futs[i].result()
+                    futs[i] = None
+                    if i + ahead < len(chunks):
+                        futs.append(self._tok_pool.submit(prep, chunks[i + ahead]))
+                    parts.append(self._forward_pool(inputs, normalize))
+                results = torch.cat(parts, dim=0)
         if isinstance(results, torch.Tensor):
             results = results.float().cpu().numpy()
         if self.embedding_config.norm and not kwargs.get("normalize", True):

@@ -29,6 +29,8 @@ class BaseConfig:
     store_format: str = "parquet"                 # "parquet" (reference behaviour) | "sidecar" (append-only files)
     embedding_cache_enabled: bool = False         # probed with hasattr by the reference (BGEEmbedding.py:57-61)
     embedding_cache_path: Optional[str] = None
+    embedding_length_bucketing: bool = True       # group a batch_encode call's prompts into mini-batches of similar token count
+    embedding_tokenizer_threads: int = 2          # host threads tokenising ahead of the forward
 
 
 def cfg_get(cfg, name, default):

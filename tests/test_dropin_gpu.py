@@ -226,6 +226,11 @@ def test_encoder_end_to_end_vs_oracle():
     t = em.encode(["what did the mother wish", "midnight"])         # positional, torch tensor (memory_utils.py:176)
     assert isinstance(t, torch.Tensor) and t.shape == (2, 128)
     np.testing.assert_allclose(em.encode_queries(["midnight"]), one, atol=1e-6)
+    # length-bucketed mini-batches (default) vs the reference's arrival-order mini-batches: same rows, same order
+    cfg2 = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=4, embedding_max_seq_len=2048, embedding_length_bucketing=False)
+    em2 = cls(global_config=cfg2, embedding_model_name=cfg2.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+    assert em._bucket and not em2._bucket
+    np.testing.assert_allclose(em2.batch_encode(texts), got, atol=2e-5)
 
 
 def test_hooks_on_a_comorag_shaped_object(golden_dir):

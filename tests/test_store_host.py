@@ -201,3 +201,23 @@ def test_tokenize_batch_equals_the_reference_tokenizer_call():
             assert got[key].dtype == ref[key].dtype == torch.int64 and torch.equal(got[key], ref[key]), key
     one = tokenize_batch(tok, [texts[0]], 512)
     assert one["input_ids"].ndim == 2 and one["input_ids"].shape[0] == 1
+
+
+def test_length_bucketing_builds_the_tokenizers_own_tensors():
+    """tokenize_ragged + pad_batch (length-bucketed mini-batches) must give, for any group of prompts, exactly the
+    tensors `tokenizer(group, padding=True, truncation=True, max_length=..., return_tensors="pt")` gives."""
+    import torch
+    from comorag_amd.embedding_model.bge import pad_batch, tokenize_ragged
+    from tools.synthetic import synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer()
+    chunks = synthetic_chunks(words, 6)
+    texts = [chunks[0][:40], chunks[1], "", "a", chunks[2][:300], chunks[3] * 2, "  ", chunks[4][:90]]
+    for max_length in (512, 24):
+        rag = tokenize_ragged(tok, texts, max_length)
+        order = np.argsort([len(x) for x in rag], kind="stable")
+        for g in (order[:3], order[3:6], order[6:]):
+            ref = tok([texts[j] for j in g], padding=True, truncation=True, max_length=max_length, return_tensors="pt")
+            got = pad_batch(tok, [rag[j] for j in g])
+            assert set(got.keys()) == set(ref.keys())
+            for key in ref:
+                assert torch.equal(got[key], ref[key]), (key, max_length)
