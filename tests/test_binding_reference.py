@@ -304,3 +304,35 @@ def test_device_ppr_hooks_on_a_real_comorag_instance(tmp_path, fake_embedder, nu
         got = ours.graph_search_with_fact_entities(q, 3, ours.get_fact_scores(q), facts, idxs, passage_node_weight=0.05)
         assert got[0].tolist() == want[0].tolist() and got[2] == want[2]
         np.testing.assert_allclose(got[1], want[1], atol=1e-9)
+
+
+def test_embedding_cache_files_are_interchangeable_with_the_reference_wrapper(tmp_path):
+    """a14 make_cache_embed (embedding_model/base.py:112-187): a cache file written by the reference's wrapper must hit
+    in ours and vice versa (same sha256 key over {"instruction", "promps" [sic], "max_length"}, same fp32 blobs)."""
+    import torch
+    from oracle.ref_loader import ref_modules
+    ref_make = ref_modules()["emb_base"].make_cache_embed
+    from comorag_amd.embedding_model.base import make_cache_embed as our_make
+    calls = []
+
+    def enc(**kw):
+        calls.append(list(kw["prompts"]))
+        return torch.tensor([[float(len(p)), float(ord(p[0])), 0.5] for p in kw["prompts"]])
+
+    f1, f2 = str(tmp_path / "ref.db"), str(tmp_path / "ours.db")
+    ref_w, our_w = ref_make(enc, f1, "cpu"), our_make(enc, f1, "cpu")
+    a = ref_w(prompts=["alpha", "be"], instruction="I", max_length=64)          # reference writes
+    calls.clear()
+    b = our_w(prompts=["be", "gamma", "alpha"], instruction="I", max_length=64)  # ours reads its entries, adds one
+    assert calls == [["gamma"]]
+    assert torch.equal(b[0], a[1]) and torch.equal(b[2], a[0]) and b.shape == (3, 3)
+    calls.clear()
+    c = ref_w(prompts=["gamma", "alpha"], instruction="I", max_length=64)        # reference reads ours
+    assert calls == [] and torch.equal(c[0], b[1])
+    our_w2, ref_w2 = our_make(enc, f2, "cpu"), ref_make(enc, f2, "cpu")          # and a file created by ours
+    d = our_w2(prompts=["delta"], instruction="", max_length=16)
+    calls.clear()
+    e = ref_w2(prompts=["delta"], instruction="", max_length=16)
+    assert calls == [] and torch.equal(d, e)
+    our_w2(prompts=["delta"], instruction="other", max_length=16)                # a different instruction is a different key
+    assert calls == [["delta"]]
