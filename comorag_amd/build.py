@@ -28,7 +28,10 @@ LIB = os.path.join(LIBDIR, "libcomorag_hip.so")
 STAMP = os.path.join(LIBDIR, "build_stamp.json")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CMR_EXTRA_HIPCC_FLAGS", "").split()
+if os.environ.get("CMR_BUILD_LIB"):          # experiment builds go to their own file (load with COMORAG_HIP_LIB=...)
+    LIB = os.environ["CMR_BUILD_LIB"]
+    STAMP = LIB + ".stamp.json"
 SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip"]
 HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 

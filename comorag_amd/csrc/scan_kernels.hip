@@ -30,6 +30,25 @@
 #define MODE_TOPK 0
 #define MODE_SCORES 1
 
+// Cache policy of the corpus stream's loads: non-temporal.  Every byte of the corpus is read once per launch by one CU,
+// so keeping the lines in L2 / MALL only evicts what the other kernels of the pipeline use; measured with
+// -DCMR_STREAM_NT=0 / 1 builds: 10 M x 768 bf16, B = 64 step 2.567 -> 2.401 ms, 1 M rows 0.294 -> 0.282 ms (the wide
+// kernel, which is not HBM-bound, does not move).
+#ifndef CMR_STREAM_NT
+#define CMR_STREAM_NT 1
+#endif
+#if CMR_STREAM_NT
+#define CMR_STREAM_POLICY " nt"
+#define CMR_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define CMR_STREAM_POLICY ""
+#define CMR_STREAM_LOAD(p) (*(p))
+#endif
+// wide kernel: 1 = all DMA pieces of a group right after its barrier, 0 = one piece per quad of blocks
+#ifndef CMR_WIDE_DMA_BURST
+#define CMR_WIDE_DMA_BURST 0
+#endif
+
 struct ScanP {
     const v4u* corpus;
     const v4u* qfrag;
@@ -203,11 +222,11 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     if constexpr ((u) < R) {                                                                               \
         if constexpr (ASMRING) {                                                                           \
             v4u slot_ = buf[(u)];                                                                        \
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                        \
+            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" CMR_STREAM_POLICY                      \
                          : "+v"(slot_) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
             buf[(u)] = slot_;                                                                              \
         } else {                                                                                           \
-            buf[(u)] = src[(size_t)(u) * 64];                                                              \
+            buf[(u)] = CMR_STREAM_LOAD(&src[(size_t)(u) * 64]);                                            \
         }                                                                                                  \
     }
 #define CMR_RING_STEP(u)                                                                                   \
@@ -692,7 +711,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
         // one DMA piece: 1 KiB from (wave-uniform base + voff) to LDS byte address dst
         auto dma_piece = [&](const char* base, unsigned dst) {
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" CMR_STREAM_POLICY "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
         };
         // prologue: groups 0 .. NST-2 of this workgroup's stream (clamped to its last group)
@@ -732,7 +751,14 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                 // matrix pipe has (tools/probe/mfma_probe.hip: 1.45 PFLOP/s chip-wide against 1.83 for runs of four).
 #pragma unroll
                 for (int qd = 0; qd < GRP / 4; ++qd) {
-                    if (ABL != 2 && ABL != 6 && ABL != 7) dma_piece(dsrc + qd * WIDE_WAVES * 1024, ddst + (unsigned)qd * WIDE_WAVES * 1024u);
+                    if (ABL != 2 && ABL != 6 && ABL != 7) {
+                        if (CMR_WIDE_DMA_BURST) {
+                            if (qd == 0)
+                                for (int j = 0; j < PPG; ++j) dma_piece(dsrc + j * WIDE_WAVES * 1024, ddst + (unsigned)j * WIDE_WAVES * 1024u);
+                        } else {
+                            dma_piece(dsrc + qd * WIDE_WAVES * 1024, ddst + (unsigned)qd * WIDE_WAVES * 1024u);
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
