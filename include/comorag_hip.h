@@ -119,8 +119,9 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t n
  * on two streams owned by the index: query packing + sampling passes of batch i+1 overlap the
  * HBM-bound main scan of batch i (main scans themselves are serialised and leave a few CUs free
  * for that).  wait_event (hipEvent_t or NULL): inputs are ready when it completes.  *done_event
- * (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded two
- * pipelined calls later, so wait on it (hipStreamWaitEvent / hipEventSynchronize) before then.
+ * (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded three
+ * pipelined calls later (the pipeline has three slots), so wait on it (hipStreamWaitEvent /
+ * hipEventSynchronize) before then.
  * k <= CMR_MAX_K.  Results are identical to cmr_index_search_dev.                               */
 int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
                                    int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
