@@ -32,6 +32,10 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 if os.environ.get("CMR_BUILD_LIB"):          # experiment builds go to their own file (load with COMORAG_HIP_LIB=...)
     LIB = os.environ["CMR_BUILD_LIB"]
     STAMP = LIB + ".stamp.json"
+# The wide kernel's panel loop (3 groups x 4 quads x 8 MFMAs with the epilogue pieces between them) must be unrolled
+# completely — every register index is a constant only then; with the slow path inlined at two places of it, its
+# unrolled size exceeds LLVM's default limit for "#pragma unroll" (16 K) and hipcc silently keeps the loops.
+SCAN_FLAGS = ["-mllvm", "-pragma-unroll-threshold=1048576"]
 SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip"]
 HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 
@@ -117,9 +121,9 @@ _WIDE_RE = re.compile(r"^_Z16scan_wide_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi
 def audit_wide(asm_text: str) -> dict:
     """The wide kernel keeps 384 registers of query fragments resident and issues its MFMAs as inline asm (hipcc pads
     no hazards around them).  Per scan_wide_kernel<DT,KS,NT,CAP,NST,KLDS> require: no scratch traffic at all (a spill
-    reload inside the panel loop would drain the hand-counted DMA ring), no v_accvgpr_write and at most 16*NT
-    v_accvgpr_read (the epilogue's reads of the accumulators: anything more means fragments are being shuttled
-    between the register files in front of the MFMAs), and no compiler VALU write of an MFMA A/B operand register
+    reload inside the panel loop would drain the hand-counted DMA ring), no v_accvgpr_write and no more v_accvgpr_read
+    than the epilogue instances account for (anything more means fragments are being shuttled between the register
+    files in front of the MFMAs), and no compiler VALU write of an MFMA A/B operand register
     in the three instructions before an asm MFMA (VALU write -> MFMA read needs wait states hipcc does not insert).
     Returns {(dt,ks,nt,cap): problem string or ''}."""
     result = {}
@@ -144,9 +148,16 @@ def audit_wide(asm_text: str) -> dict:
             problems.append("scratch traffic")
         if any(c.startswith("v_accvgpr_write") for c in code):
             problems.append("v_accvgpr_write")
+        # Accumulator reads.  An epilogue instance reads a tile's 16 accumulator registers in up to four places: the
+        # min / max fold, the (cold) masked fold of the corpus' last panel and the two (cold) candidate pushes (sampling
+        # pass / main pass).  NT = 1 has one instance (fold and main-pass push share their reads), the software-pipelined
+        # NT = 2 kernel three (tile 0, tile 1 inside the next panel's first quad, tile 1 of the last panel after the
+        # loop).  Anything beyond that means query fragments are being shuttled between the register files in front of
+        # the MFMAs.
         n_read = sum(c.startswith("v_accvgpr_read") for c in code)
-        if n_read > 16 * nt:
-            problems.append(f"{n_read} v_accvgpr_read > {16 * nt}")
+        lim_read = 64 * 3 if nt == 2 else 48
+        if n_read > lim_read:
+            problems.append(f"{n_read} v_accvgpr_read > {lim_read}")
         n_mfma = 0
         for n, c in enumerate(code):
             if not c.startswith("v_mfma"):
@@ -175,7 +186,7 @@ def _source_hash() -> str:
     for f in SOURCES + HEADERS + [os.path.join("..", "build.py")]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + SCAN_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -193,7 +204,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with tempfile.TemporaryDirectory(prefix="cmr_build_") as tmp:
         objs = []
         # 1. scan kernels with assembly kept
-        _run([HIPCC, *FLAGS, "-save-temps", "-c", os.path.join(CSRC, "scan_kernels.hip"), "-o", "scan_kernels.o"], cwd=tmp)
+        _run([HIPCC, *FLAGS, *SCAN_FLAGS, "-save-temps", "-c", os.path.join(CSRC, "scan_kernels.hip"), "-o", "scan_kernels.o"], cwd=tmp)
         objs.append(os.path.join(tmp, "scan_kernels.o"))
         asm_file = os.path.join(tmp, f"scan_kernels-hip-amdgcn-amd-amdhsa-{ARCH}.s")
         audit = audit_ring(open(asm_file).read())

@@ -23,6 +23,7 @@
 //    when a list is nearly full, compact it to its k best (rank by counting) and raise tau.
 //    Expected pushes per query per wave are k*ln(rows/k): the slow path is rare by construction.
 #include <cstdlib>
+#include <type_traits>
 
 #include "cmr_device.h"
 #include "cmr_kernels.h"
@@ -445,20 +446,37 @@ __device__ __forceinline__ float wide_min3(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
-// panel max (returned) and running min / max of one tile's 16 scores per lane
-__device__ __forceinline__ float wide_minmax(const f32x16& acc, float& rmin, float& rmax) {
-    float mx = -__builtin_inff(), mn = rmin;
+// panel max (returned) and running min / max of one tile's 16 scores per lane; gmax[i] = max of accumulator registers
+// 4i .. 4i+3 (the slow path only looks into the quarters that beat the threshold)
+__device__ __forceinline__ float wide_minmax(const f32x16& acc, float& rmin, float& rmax, float (&gmax)[4]) {
+    float mn = rmin;
 #pragma unroll
-    for (int r = 0; r < 16; r += 4) {
-        mx = wide_max3(mx, acc[r], acc[r + 1]);
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * i;
+        gmax[i] = wide_max3(acc[r], acc[r + 1], acc[r + 2]);
         mn = wide_min3(mn, acc[r], acc[r + 1]);
-        mx = wide_max3(mx, acc[r + 2], acc[r + 3]);
+        gmax[i] = wide_max3(gmax[i], acc[r + 3], acc[r + 3]);
         mn = wide_min3(mn, acc[r + 2], acc[r + 3]);
         __builtin_amdgcn_sched_barrier(0);
     }
     rmin = mn;
+    const float mx = wide_max3(wide_max3(gmax[0], gmax[1], gmax[2]), gmax[3], gmax[3]);
     rmax = wide_max3(rmax, mx, mx);
     return mx;
+}
+// One quarter of wide_minmax, issued BETWEEN two MFMAs of the other tile (NT = 2): four accumulator values folded into the
+// panel max / min.  With one wave per SIMD nothing else can use the matrix pipe while this wave runs VALU code, so the
+// epilogue is software-pipelined into the MFMA stream: an independent MFMA occupies the pipe for 8 issue slots, seven of
+// which are free for these eight instructions.
+__device__ __forceinline__ void wide_epi_piece(const f32x16& acc, int i, float& gmax, float& mn) {
+    // one statement: hipcc would otherwise read every accumulator value twice (one AGPR -> VGPR copy per consumer) and
+    // keep all sixteen alive for the (cold) partial-panel branch
+    float a0, a1, a2, a3;
+    asm volatile("v_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7\n\tv_accvgpr_read_b32 %4, %8\n\tv_accvgpr_read_b32 %5, %9\n\t"
+                 "v_max3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %1, %2, %3\n\tv_max_f32 %0, %0, %5\n\tv_min3_f32 %1, %1, %4, %5"
+                 : "=&v"(gmax), "+v"(mn), "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+                 : "a"(acc[4 * i]), "a"(acc[4 * i + 1]), "a"(acc[4 * i + 2]), "a"(acc[4 * i + 3]));
+    __builtin_amdgcn_sched_barrier(0);
 }
 // the same for the corpus' last, partial panel: rows >= nvalid are padding
 __device__ __forceinline__ float wide_minmax_partial(const f32x16& acc, int nvalid, int lane, float& rmin, float& rmax) {
@@ -548,12 +566,15 @@ __device__ __forceinline__ u64 wide_push(const f32x16& acc, unsigned row0, int n
     const int c = __hip_atomic_load(&cnt_t[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __ballot(c > CAP - 32) & 0xFFFFFFFFull;
 }
-// The same push for the MAIN pass, where a tile that beats the threshold does so with one or two values: one value at
-// a time behind the float pre-filter (a whole wave usually skips the register), key compare for the ties, one
-// returning LDS atomic and one store per pushed value; n_stores counts the store instructions.
-template <int CAP>
-__device__ __forceinline__ u64 wide_push_sparse(const f32x16& acc, unsigned row0, int nvalid, u64 tau_key, float tau_f, int* cnt_t, u64* list_t,
-                                                int lane, int& n_stores) {
+// The same push for the MAIN pass, where a tile that beats the threshold does so with one or two values (the threshold
+// comes from a 300 K-row sample: ~640 of a query's 10 M scores pass, 2-3 per workgroup).  At 256 queries per workgroup
+// one panel in two has such an event in SOME wave and the other three wait for it at the next group barrier, so the
+// event is kept short: only the accumulator quarters whose maximum (gmax, from the epilogue's fold) reaches the
+// threshold are read back and scanned, one wave-uniform test per register, key compare for the ties, one returning LDS
+// atomic and one store per pushed value; n_stores counts the store instructions.
+template <int CAP, bool ASMREAD>
+__device__ __forceinline__ u64 wide_push_sparse(const f32x16& acc, const float (&gmax)[4], unsigned row0, int nvalid, u64 tau_key, float tau_f,
+                                                int* cnt_t, u64* list_t, int lane, int& n_stores) {
     int ql = lane & 31;
     int hrow = 4 * (lane >> 5);
     asm volatile("" : "+v"(ql), "+v"(hrow));
@@ -561,20 +582,30 @@ __device__ __forceinline__ u64 wide_push_sparse(const f32x16& acc, unsigned row0
     const int lim = nvalid - hrow;
     int top = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v = acc[r];
-        if (v >= tau_f) {
-            const int cr = (r & 3) + 8 * (r >> 2);
-            const u64 key = cmr_make_key(v, rbase + (unsigned)cr);
-            const bool hit = cr < lim && key > tau_key;
-            n_stores += __any(hit) ? 1 : 0;
-            if (hit) {
-                const int slot = atomicAdd(&cnt_t[ql], 1);  // ds_add_rtn_u32; <= 32 pushes per query per panel
-                list_t[(size_t)ql * CAP + slot] = key;
-                top = slot + 1;
+    for (int gi = 0; gi < 4; ++gi) {
+        if (__any(gmax[gi] >= tau_f)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * gi + j;
+                float v;
+                // ASMREAD (software-pipelined NT = 2 kernel): the read stays inside this branch; otherwise the caller's fold
+                // already holds the sixteen values in VGPRs
+                if constexpr (ASMREAD) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(acc[r]));
+                else v = acc[r];
+                if (__any(v >= tau_f)) {
+                    const int cr = (r & 3) + 8 * (r >> 2);
+                    const u64 key = cmr_make_key(v, rbase + (unsigned)cr);
+                    const bool hit = v >= tau_f && cr < lim && key > tau_key;
+                    n_stores += __any(hit) ? 1 : 0;
+                    if (hit) {
+                        const int slot = atomicAdd(&cnt_t[ql], 1);  // ds_add_rtn_u32; <= 32 pushes per query per panel
+                        list_t[(size_t)ql * CAP + slot] = key;
+                        top = slot + 1;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
     // the atomics returned each pushing lane's slot: a list is nearly full when some push landed beyond CAP - 32
     const u64 full = __ballot(top > CAP - 32);
@@ -732,13 +763,59 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
 #pragma unroll
         for (int u = 0; u < ADEPTH; ++u) a[u] = buf[u * 64];
 
+        // Epilogue schedule.  NT = 1: after the panel's MFMAs (drain, min / max, threshold test).  NT = 2: software-pipelined
+        // into the MFMA stream, because with one wave per SIMD the matrix pipe idles whenever this wave runs VALU code —
+        // tile 0's min / max sits between tile 1's last four MFMAs of the panel, tile 1's between the first four tile-0
+        // MFMAs of the NEXT panel (tile 1's accumulators stay untouched until that quad's own tile-1 MFMAs), the last
+        // panel's after the loop.  No accumulator is duplicated; the threshold test and the (rare) slow path follow the
+        // fold at once, so a tile's pushes still precede the next panel's compare for that tile.
+        f32x16 acc[NT];
+        if constexpr (NT == 2) asm volatile("" : "=a"(acc[1]));   // the very first quad folds (and discards) whatever is there
+        float eg[4] = {0.0f, 0.0f, 0.0f, 0.0f}, emn = 0.0f;   // quarter maxima / panel min under construction by the interleaved pieces
+        unsigned prow0 = 0;                           // the previous panel: tile 1's epilogue is still pending
+        int pnvalid = CMR_PANEL_ROWS;
+        int st_mid = 0;                               // NT = 2: store instructions of tile 0's epilogue of the previous panel
+        // fold + threshold test + slow path of tile tc; FOLDED: emx / emn already hold the panel's max / min
+        auto epi_finish = [&](auto tc, auto folded, unsigned row0, int nvalid, int& n_stores, bool& compacted) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+            float mx;
+            if (__builtin_expect(nvalid < CMR_PANEL_ROWS, 0)) {        // only the corpus' last panel: masked re-computation
+                asm volatile("" : "+s"(nvalid), "+a"(acc[t]));         // keeps the masked variant's arithmetic and accumulator reads inside this branch
+                mx = wide_minmax_partial(acc[t], nvalid, lane, rmin[t], rmax[t]);
+                eg[0] = eg[1] = eg[2] = eg[3] = mx;                    // the slow path looks everywhere
+            } else if (decltype(folded)::value) {
+                mx = wide_max3(wide_max3(eg[0], eg[1], eg[2]), eg[3], eg[3]);
+                rmin[t] = wide_min3(rmin[t], emn, emn);
+                rmax[t] = wide_max3(rmax[t], mx, mx);
+            } else {
+                mx = wide_minmax(acc[t], rmin[t], rmax[t], eg);
+            }
+            if (ABL != 4 && __any(mx >= tau_f[t])) {
+                // (opaque: hipcc must not hoist the slow path's sixteen accumulator reads in front of the test)
+                if constexpr (decltype(folded)::value) asm volatile("" : "+a"(acc[t]));
+                // sampling pass: dense hits (threshold from a small sample) -> staged push; main pass: sparse hits
+                const u64 need = P.sample_waves > 0
+                    ? wide_push<CAP>(acc[t], row0, nvalid, tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, stg, stg_tail, lane, n_stores)
+                    : wide_push_sparse<CAP, decltype(folded)::value>(acc[t], eg, row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane, n_stores);
+                if (need) {
+                    wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
+                    compacted = true;
+                }
+            }
+        };
+        using T0 = std::integral_constant<int, 0>;
+        using T1 = std::integral_constant<int, NT - 1>;
+
         for (int s = s0; s < s1; ++s) {
-            f32x16 acc[NT];
+            const unsigned row0 = panel_of(s) * CMR_PANEL_ROWS;                         // < 2^32 rows per shard (cmr_index_append)
+            int nvalid = CMR_PANEL_ROWS;
+            if (__builtin_expect((long long)row0 + CMR_PANEL_ROWS > P.nrows, 0)) nvalid = (int)(P.nrows - (long long)row0);
 #pragma unroll
             for (int g = 0; g < GPP; ++g) {
-                // the DMA pieces of group g+1 were issued NST-2 groups (two panels) ago: the store instructions of the
-                // last two epilogues are younger than they are
-                if constexpr (ABL != 2 && ABL != 6 && ABL != 7) wide_wait_group<PPG * (NST - 3)>(st_new + st_old);
+                // The DMA pieces of group g+1 were issued NST-2 groups (two panels) ago; the store instructions issued since
+                // are younger than they are: NT = 1 the last two epilogues'; NT = 2 the same, except that at g = 0 tile 1's
+                // epilogue of the previous panel has not run yet (it sits in this group's first quad).
+                if constexpr (ABL != 2 && ABL != 6 && ABL != 7) wide_wait_group<PPG * (NST - 3)>(st_old + ((NT == 2 && g == 0) ? st_mid : st_new));
                 if constexpr (ABL != 5 && ABL != 7) asm volatile("s_barrier" ::: "memory");
                 // prefetch cursor: group g + NST-1 of the stream, into the stage everybody just left
                 const int dps = s + (g + NST - 1) / GPP;
@@ -781,6 +858,43 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                                 const v4u b = qlds[(t * KLDS + (ks < KREG ? 0 : ks - KREG)) * 64];
                                 CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
                             }
+                            if constexpr (NT == 2 && ABL != 3) {
+                                // (g, qd, t, j are constants after unrolling: at most one of these survives per MFMA)
+                                if (g == 0 && qd == 0 && t == 0) {                  // tile 1 of the PREVIOUS panel, under this panel's first tile-0 MFMAs
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    if (j == 0) {
+                                        // MFMA result -> VALU reader needs 12 wait states after the producer's issue, which hipcc does
+                                        // not pad for asm: the producer (tile 1's last MFMA of the previous panel) is tile 0's tail
+                                        // pieces, four LDS reads, a counted wait, a barrier, a DMA statement and an MFMA back
+                                        asm volatile("" : "+a"(acc[NT - 1]));
+                                        emn = __builtin_inff();
+                                    }
+                                    wide_epi_piece(acc[NT - 1], j, eg[j], emn);
+                                    if (j == 3) {
+                                        int n1 = 0;
+                                        bool comp = false;
+                                        if (s > s0) epi_finish(T1{}, std::true_type{}, prow0, pnvalid, n1, comp);
+                                        st_new = st_mid + __builtin_amdgcn_readfirstlane(n1);
+                                        if (comp) {     // its loads already drained the ring; retire its stores too and restart the counts
+                                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                            st_old = st_new = 0;
+                                        }
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    }
+                                }
+                                if (g == GPP - 1 && qd == GRP / 4 - 1 && t == NT - 1) {   // tile 0 of THIS panel, under tile 1's last MFMAs
+                                    __builtin_amdgcn_sched_barrier(0);
+                                    // The producer is tile 0's last MFMA, directly in front of tile 1's four.  Tile 1's second MFMA
+                                    // depends on its first, so it issues >= 8 states after it whatever the pipe does with independent
+                                    // MFMAs: the first piece goes behind the SECOND MFMA, two more states make 12 by construction.
+                                    if (j == 1) {
+                                        asm volatile("s_nop 1" : "+a"(acc[0]));
+                                        emn = __builtin_inff();
+                                    }
+                                    if (j >= 1) wide_epi_piece(acc[0], j - 1, eg[j - 1 < 0 ? 0 : j - 1], emn);
+                                    if (j == 3) wide_epi_piece(acc[0], 3, eg[3], emn);
+                                }
+                            }
                         }
                     // the quad's four ring slots take the blocks ADEPTH ahead (they land under the next quad's MFMAs)
                     if constexpr (ABL != 6) {
@@ -795,39 +909,41 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                 st = stn;
                 buf = bufn;
             }
-            cmr_mfma_drain<NT>(acc);          // MFMA results -> VALU readers: wait states hipcc does not insert for asm
-            if constexpr (ABL == 3) continue;
-
-            const unsigned row0 = panel_of(s) * CMR_PANEL_ROWS;                         // < 2^32 rows per shard (cmr_index_append)
-            int nvalid = CMR_PANEL_ROWS;
-            const bool partial = (long long)row0 + CMR_PANEL_ROWS > P.nrows;            // only the corpus' last panel
-            if (__builtin_expect(partial, 0)) {
-                nvalid = (int)(P.nrows - (long long)row0);
-                asm volatile("" : "+s"(nvalid));      // keeps the masked variant's arithmetic inside this branch
+            if constexpr (ABL == 3) {
+                if constexpr (NT == 1) cmr_mfma_drain<NT>(acc);
+                continue;
             }
             int n_stores = 0;
             bool compacted = false;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float mx = __builtin_expect(partial, 0) ? wide_minmax_partial(acc[t], nvalid, lane, rmin[t], rmax[t])
-                                                              : wide_minmax(acc[t], rmin[t], rmax[t]);
-                if (ABL != 4 && __any(mx >= tau_f[t])) {
-                    // sampling pass: dense hits (threshold from a small sample) -> staged push; main pass: sparse hits
-                    const u64 need = P.sample_waves > 0
-                        ? wide_push<CAP>(acc[t], row0, nvalid, tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, stg, stg_tail, lane, n_stores)
-                        : wide_push_sparse<CAP>(acc[t], row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane, n_stores);
-                    if (need) {
-                        wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
-                        compacted = true;
-                    }
+            if constexpr (NT == 1) {
+                cmr_mfma_drain<NT>(acc);          // MFMA results -> VALU readers: wait states hipcc does not insert for asm
+                epi_finish(T0{}, std::false_type{}, row0, nvalid, n_stores, compacted);
+                st_old = st_new;
+                st_new = __builtin_amdgcn_readfirstlane(n_stores);
+                if (compacted) {        // its loads already drained the ring; retire its stores too and restart the count
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_old = st_new = 0;
                 }
+            } else {
+                epi_finish(T0{}, std::true_type{}, row0, nvalid, n_stores, compacted);
+                st_old = st_new;
+                st_mid = __builtin_amdgcn_readfirstlane(n_stores);
+                if (compacted) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    st_old = st_mid = 0;
+                }
+                prow0 = row0;
+                pnvalid = nvalid;
             }
-            st_old = st_new;
-            st_new = __builtin_amdgcn_readfirstlane(n_stores);
-            if (compacted) {        // its loads already drained the ring; retire its stores too and restart the count
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                st_old = st_new = 0;
-            }
+        }
+        if constexpr (NT == 2 && ABL != 3) {      // tile 1 of the last panel
+            asm volatile("s_nop 15" : "+a"(acc[NT - 1]));
+            emn = __builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wide_epi_piece(acc[NT - 1], j, eg[j], emn);
+            int n1 = 0;
+            bool comp = false;
+            epi_finish(T1{}, std::true_type{}, prow0, pnvalid, n1, comp);
         }
     }
 
