@@ -108,6 +108,8 @@ struct Workspace {
 
 struct ProfEvent { hipEvent_t a, b; };
 
+constexpr size_t kZeroCopyMax = 256 * 1024;   // synchronous host API: queries / results up to this size are mapped, not copied
+
 struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullptr, main_done = nullptr; bool used = false; };
 #define CMR_PIPE_SLOTS 4
 struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sq = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; };
@@ -141,6 +143,8 @@ struct cmr_index {
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch path for corpora of <= 1024 rows
+    int single_level = 1;    // CMR_SAMPLE_SINGLE=0: small batches on mid-size corpora sample in two levels like everything else
+    int zero_copy = 1;       // CMR_ZERO_COPY=0: the synchronous host API copies queries / results instead of mapping them
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
     int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
@@ -326,8 +330,13 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     // sampling passes
     if (!idx->no_sample && npanels >= 256 && !min_score) {
         const long long s0 = std::max<long long>(16, k);                       // panels
-        level_panels[n_levels++] = s0;
-        if (npanels >= 4096) {
+        // A handful of queries on a mid-size corpus (what a synchronous caller issues) is a chain of dependent launches
+        // around a short scan: ONE sampling level of 128 panels instead of two saves a scan + merge pair (~45 us of a
+        // 0.4 ms call at 1 M rows).  Its threshold lets ~k * npanels / 128 scores per query through — a few slow-path
+        // entries per wave as long as queries x panels stays small.
+        const bool single_level = !wide && idx->single_level && k <= 32 && nqp <= 8 && npanels >= 4096 && (long long)nqp * npanels <= 320000;
+        level_panels[n_levels++] = single_level ? 128 : s0;
+        if (npanels >= 4096 && !single_level) {
             // wide kernel: 256 queries share a workgroup, so ANY of 8 tiles beating its threshold stalls all four waves at
             // the next barrier — a 4x larger level-1 sample (N/32 rows up to 512 x level 0) took the main pass from 4.09 to
             // 3.76 ms at 10 M rows; the sample itself is cheap there (256 queries per pass over it)
@@ -715,6 +724,8 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->force_grid = env_int("CMR_SCAN_GRID", 0);
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
+    idx->zero_copy = env_int("CMR_ZERO_COPY", 1);
+    idx->single_level = env_int("CMR_SAMPLE_SINGLE", 1);
     idx->no_tiny = env_int("CMR_SCAN_NO_TINY", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
     idx->pipe_slots = env_int("CMR_PIPE_SLOTS", 3);
@@ -919,31 +930,60 @@ static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t
     if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
     struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
     hipStream_t s = ws->stream;
-    // packed device buffer [flag (8 B) | ids nq*k i64 | scores nq*k f32 | min nq | max nq] and its pinned host twin; the
-    // queries go through the pinned buffer too (a pageable H2D is staged by the runtime anyway)
+    // packed result buffer [flag (8 B) | ids nq*k i64 | scores nq*k f32 | min nq | max nq]
     const size_t o_ids = 8, o_sc = o_ids + (size_t)nq * k * 8, o_min = o_sc + (size_t)nq * k * 4, o_max = o_min + (size_t)nq * 4,
                  out_bytes = o_max + (size_t)nq * 4, q_bytes = (size_t)nq * idx->dim * 4;
-    HIP_TRY(ws->d_q.ensure(q_bytes));
-    if (out_bytes > ws->d_pack.cap || !ws->d_pack.p) {        // (re)allocation moves the flag: re-arm it at the new place
+    const char* hp = nullptr;
+    if (idx->zero_copy && k <= CMR_MAX_K && q_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax) {
+        // Small calls (what ComoRAG issues: one query, a few hundred rows) are all latency.  A copy each way costs two more
+        // submissions in front of / behind the kernels (36 us per call at 6 rows, of which the search itself is ~8); so
+        // there are none: queries, results and the non-finite flag live in ONE pinned, device-mapped host buffer
+        // (fine-grained: kernel stores are visible once the stream has been synchronised) that the kernels read and
+        // write over PCIe themselves — a few KiB either way.
+        const size_t o_q = (out_bytes + 255) & ~(size_t)255;
+        HIP_TRY(ws->ensure_pin(o_q + q_bytes));
+        char* h = (char*)ws->h_pin;
+        char* d = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void**)&d, h, 0));
+        memcpy(h + o_q, q, q_bytes);
+        memset(h, 0, 8);
+        int* const dev_flag = ws->flag_ptr;
+        ws->flag_ptr = (int*)d;
+        rc = search_enqueue(idx, ws, (const float*)(d + o_q), nq, k, (int64_t*)(d + o_ids), (float*)(d + o_sc), (float*)(d + o_min), (float*)(d + o_max), min_score);
+        ws->flag_ptr = dev_flag;
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
         HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(ws->d_pack.ensure(std::max<size_t>(out_bytes, 4096)));
-        HIP_TRY(hipMemsetAsync(ws->d_pack.p, 0, 8, s));
+        hp = h;
+        int flagged = 0;
+        memcpy(&flagged, hp, sizeof(int));
+        if (flagged) return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+    } else {
+        // packed device buffer and its pinned host twin, one copy each way; the queries go through the pinned buffer too (a
+        // pageable H2D is staged by the runtime anyway)
+        HIP_TRY(ws->d_q.ensure(q_bytes));
+        if (out_bytes > ws->d_pack.cap || !ws->d_pack.p) {        // (re)allocation moves the flag: re-arm it at the new place
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(ws->d_pack.ensure(std::max<size_t>(out_bytes, 4096)));
+            HIP_TRY(hipMemsetAsync(ws->d_pack.p, 0, 8, s));
+        }
+        int* const dev_flag = ws->flag_ptr;
         ws->flag_ptr = (int*)ws->d_pack.p;
-    }
-    HIP_TRY(ws->ensure_pin(std::max(out_bytes, q_bytes)));
-    memcpy(ws->h_pin, q, q_bytes);
-    HIP_TRY(hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s));
-    char* pk = (char*)ws->d_pack.p;
-    rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max), min_score);
-    if (rc) { (void)hipStreamSynchronize(s); return rc; }
-    HIP_TRY(hipMemcpyAsync(ws->h_pin, pk, out_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    const char* hp = (const char*)ws->h_pin;
-    int flagged = 0;
-    memcpy(&flagged, hp, sizeof(int));
-    if (flagged) {
-        HIP_TRY(hipMemsetAsync(ws->flag_ptr, 0, sizeof(int), s));
-        return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+        HIP_TRY(ws->ensure_pin(std::max(out_bytes, q_bytes)));
+        memcpy(ws->h_pin, q, q_bytes);
+        HIP_TRY(hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s));
+        char* pk = (char*)ws->d_pack.p;
+        rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max), min_score);
+        ws->flag_ptr = dev_flag;
+        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        HIP_TRY(hipMemcpyAsync(ws->h_pin, pk, out_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        hp = (const char*)ws->h_pin;
+        int flagged = 0;
+        memcpy(&flagged, hp, sizeof(int));
+        if (flagged) {
+            HIP_TRY(hipMemsetAsync(ws->d_pack.p, 0, sizeof(int), s));
+            return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+        }
     }
     memcpy(out_ids, hp + o_ids, (size_t)nq * k * 8);
     memcpy(out_scores, hp + o_sc, (size_t)nq * k * 4);

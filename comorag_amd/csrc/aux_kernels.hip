@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     bool bad = false;
     const uint4 v = cmr_pack_slot<DT>(qi < nq ? q + (size_t)qi * dim : nullptr, dim, ks, lane, bad);
     qfrag[(size_t)blk * 64 + lane] = v;
-    if (bad) atomicOr(flag, 1);
+    if (bad) *(volatile int*)flag = 1;     // plain store (every writer writes 1): the flag may live in mapped host memory
 }
 
 // tau[i] = (smallest candidate key whose score is >= min_score) - 1, so that key > tau <=> score >= min_score
@@ -146,7 +146,7 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 // suffix scan finds the digit that contains the k-th largest key, and the prefix grows by one byte;
 // after the last pass the prefix IS the k-th largest key (keys are unique).  Keys >= it are
 // collected (exactly k of them) and ordered by rank counting.  Cost is independent of k.
-//   scratch: hist[256] ints, wsum[MERGE_WAVES] ints, sel[2] ints, cnt int, cand[k] u64
+//   scratch: hist[256] ints, wsum[MERGE_WAVES] ints, sel[4] ints (digit, k_rem, winner counter, bin count), cand[k] u64
 __device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1], int k, int* hist, int* wsum, int* sel,
                                                   u64* cand, u64* res) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,11 +204,15 @@ __device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1]
             for (int w = 0; w < MERGE_WAVES; ++w) higher += w > wave ? wsum[w] : 0;
             const int S = s + higher;        // keys whose digit >= tid
             const int Sgt = S - c;           // keys whose digit >  tid
-            if (S >= k_rem && Sgt < k_rem) { sel[0] = tid; sel[1] = k_rem - Sgt; }
+            if (S >= k_rem && Sgt < k_rem) { sel[0] = tid; sel[1] = k_rem - Sgt; sel[3] = c; }
             __syncthreads();
             pval |= (u64)(unsigned)sel[0] << shift;
             pmask |= 0xFFull << shift;
             k_rem = sel[1];
+            // Every key that still matches the prefix is wanted: done — the prefix with zero low bits separates the
+            // winners from the rest.  Scores are almost unique, so this is the rule after three or four of the eight
+            // passes (the low word of a key is the row: it only ever decides ties).
+            if (sel[3] == k_rem) break;
         }
         thr = pval;
     }
@@ -393,18 +397,35 @@ template <int DT>
 __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict__ corpus, const float* __restrict__ q, int nq, int dim, int ks_total,
                                                           int nrows, int npanels, int k, long long id_base, float* __restrict__ scratch,
                                                           int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                          float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag) {
+                                                          float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag, int stage_raw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64]
+    uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64], then (stage_raw) the fp32 queries [nq][dim]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqt = (nq + 31) / 32;
     bool bad = false;
+    // The synchronous host API maps the queries from pinned host memory (no copy in front of the launch): fetch them with
+    // independent, unconditional loads — eight in flight per thread, one PCIe round trip for a single query — into LDS
+    // and pack from there; packing straight from q would walk the link once per dependent conditional load.
+    const float* qsrc = q;
+    if (stage_raw) {
+        float* qraw = reinterpret_cast<float*>(sm + (size_t)nqt * ks_total * 1024);
+        const int nflt = nq * dim;
+        for (int i0 = tid; i0 < nflt; i0 += 8 * 512) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512; v[u] = q[i < nflt ? i : nflt - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 512; if (i < nflt) qraw[i] = v[u]; }
+        }
+        __syncthreads();
+        qsrc = qraw;
+    }
     for (int i = tid; i < nqt * ks_total * 64; i += 512) {
         const int l = i & 63, ks = (i >> 6) % ks_total, t = (i >> 6) / ks_total;
         const int qi = t * 32 + (l & 31);
-        qf[i] = cmr_pack_slot<DT>(qi < nq ? q + (size_t)qi * dim : nullptr, dim, ks, l, bad);
+        qf[i] = cmr_pack_slot<DT>(qi < nq ? qsrc + (size_t)qi * dim : nullptr, dim, ks, l, bad);
     }
-    if (bad) atomicOr(flag, 1);
+    if (bad) *(volatile int*)flag = 1;     // plain store (every writer writes 1): the flag may live in mapped host memory
     __syncthreads();
     const int ld = npanels * CMR_PANEL_ROWS;
     const v4u* qv = reinterpret_cast<const v4u*>(qf);
@@ -473,15 +494,17 @@ hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q,
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     const int nqt = (nq + 31) / 32;
-    const size_t lds = (size_t)nqt * ks * 1024;
+    size_t lds = (size_t)nqt * ks * 1024;
     if (npanels > 32 || nq > 16 || lds > 160 * 1024) return hipErrorInvalidValue;
+    const int stage_raw = lds + (size_t)nq * dim * 4 <= 160 * 1024 ? 1 : 0;      // fp32 at 1024-d: the operands alone take 128 KiB
+    if (stage_raw) lds += (size_t)nq * dim * 4;
     const v4u* c = reinterpret_cast<const v4u*>(corpus);
 #define TS(DT)                                                                                                                       \
     {                                                                                                                                \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                               \
         hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(1), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scratch, out_ids, \
-                           out_scores, out_min, out_max, flag);                                                                      \
+                           out_scores, out_min, out_max, flag, stage_raw);                                                           \
     }
     switch (dtype) {
         case CMR_DT_BF16: TS(CMR_DT_BF16) break;

@@ -21,8 +21,10 @@ def _f32c(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def _ptr(a: np.ndarray):
-    return a.ctypes.data_as(C.c_void_p)
+def _ptr(a: np.ndarray) -> int:
+    # the array's address as an int (c_void_p parameters take one): `a.ctypes.data_as(...)` builds a ctypes helper object
+    # per call, 2 us each — a third of a 35 us single-query search went into marshalling five arrays
+    return a.__array_interface__["data"][0]
 
 
 class DenseIndex:

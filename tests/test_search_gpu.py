@@ -70,6 +70,37 @@ def test_tiny_single_launch_path_equals_general_path(dtype, n, nq, k):
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
 
 
+@pytest.mark.parametrize("n,nq,k", [(6, 1, 5), (1000, 3, 20), (5000, 1, 20), (140_000, 1, 20), (140_000, 8, 20), (20_000, 64, 20), (3000, 2, 100)])
+def test_zero_copy_host_api_equals_copy_path(n, nq, k):
+    """The synchronous host API maps queries / results / the non-finite flag from pinned host memory (no copies around the
+    kernels); CMR_ZERO_COPY=0 is the one-copy-each-way path.  Both must equal the oracle and each other bit for bit; a
+    NaN query must still be reported through the mapped flag, and the call after it must be clean."""
+    from comorag_amd import _lib
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(n, 768 if n < 100_000 else 128, nq, seed=n + nq)
+    a_ids, a_sc = _check("bf16", X, Q, k)
+    b_ids, b_sc = _check("bf16", X, Q, k, env={"CMR_ZERO_COPY": "0"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+    idx = DenseIndex(X.shape[1], "bf16")
+    idx.append(X)
+    bad = Q.copy(); bad[-1, 3] = np.nan
+    with pytest.raises(_lib.CmrError):
+        idx.search(bad, k)
+    ids, sc, _, _ = idx.search(Q, k)
+    assert np.array_equal(ids, a_ids) and np.array_equal(sc, a_sc)
+    idx.close()
+
+
+@pytest.mark.parametrize("dtype,n,d,nq", [("bf16", 140_000, 128, 1), ("bf16", 140_000, 128, 8), ("f32", 131_072 + 5, 64, 3), ("bf16", 300_000, 64, 2)])
+def test_small_batch_single_level_sampling(dtype, n, d, nq):
+    """<= 8 queries on >= 128 Ki rows: one sampling level of 128 panels instead of two (CMR_SAMPLE_SINGLE=0 restores the
+    two-level scheme).  A sample threshold is a lower bound of the true k-th best whatever the sample: same results."""
+    X, Q = _mk(n, d, nq, seed=n % 1000 + nq)
+    a_ids, a_sc = _check(dtype, X, Q, 20)
+    b_ids, b_sc = _check(dtype, X, Q, 20, env={"CMR_SAMPLE_SINGLE": "0"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+
+
 @pytest.mark.parametrize("dtype,d", [("bf16", 8), ("bf16", 128), ("bf16", 768), ("bf16", 1024), ("f16", 1024),
                                      ("f32", 768), ("f32", 100), ("bf16", 200)])
 def test_dims(dtype, d):
