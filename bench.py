@@ -218,6 +218,32 @@ def host_api_rate(torch, sh, Qh, k, steps=30):
     return {"value": len(Qh) * steps / dt, "unit": "queries/s", "ms_per_call": dt / steps * 1e3}
 
 
+def single_query_latency(torch, args, device, sizes=(6, 1000, 10_000, 100_000)):
+    """What ComoRAG's per-question threads issue (ComoRAG.py:937-967 is one query per call): median wall time of a
+    synchronous single-query top-k through the host-buffer API, Python wrapper included, per corpus size."""
+    from comorag_amd.index import DenseIndex
+    out = {}
+    rng = np.random.default_rng(11)
+    for rows in sizes:
+        idx = DenseIndex(args.dim, args.dtype, device=device.index or 0, capacity_hint=rows)
+        for blk in gen_rows_dev(torch, 0, rows, args.dim, device):
+            idx.append_dev(blk)
+        torch.cuda.synchronize(device)
+        q1 = rng.standard_normal((1, args.dim)).astype(np.float32)
+        q1 /= np.linalg.norm(q1)
+        kk = min(args.k, rows)
+        for _ in range(5):
+            idx.search(q1, kk)
+        t = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            idx.search(q1, kk)
+            t.append(time.perf_counter() - t0)
+        out[str(rows)] = float(np.median(t) * 1e6)
+        idx.close()
+    return {"unit": "us per call (median of 50)", "rows": out}
+
+
 def encode_rate(torch, device, kind="base", n_chunks=256, dtype="auto"):
     """Corpus-embed chunks/s: tokenise + encoder forward (PyTorch-ROCm, random-init BERT of BGE shape)
     + HIP masked mean-pool/L2-norm, batch 32, ~480-token chunks truncated to 512 positions."""
@@ -353,6 +379,18 @@ def main():
                 dt2, prof2, _ = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device)
                 extra[f"{name}_{rows2}_rows_batch{b2}"] = summarise(b2, steps2, dt2, prof2, rows2, args.dim)
             if name == "config2":
+                try:
+                    lat = single_query_latency(torch, args, device)
+                    sh2.local.search(qh[:1], args.k)
+                    t1 = []
+                    for _ in range(30):
+                        t0 = time.perf_counter()
+                        sh2.local.search(qh[:1], args.k)
+                        t1.append(time.perf_counter() - t0)
+                    lat["rows"][str(rows2)] = float(np.median(t1) * 1e6)
+                    extra["single_query_latency"] = lat
+                except Exception as e:
+                    extra["single_query_latency"] = {"error": repr(e)[:300]}
                 extra["host_buffer_api"] = host_api_rate(torch, sh2, qh, args.k)
                 extra["host_buffer_api"]["note"] = f"PCIe-inclusive: {rows2} rows, H2D queries + D2H results + sync per call"
                 try:        # complete ranking of one query (dense_passage_retrieval's all-N return): scan + device radix sort + D2H

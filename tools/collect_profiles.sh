@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 profile collection on the GPU box (gpurun): kernel trace of bench.py, PMC traffic passes of the headline
-# configuration, SQ counters of the wide kernel.  Summaries land in gpurun_out/r2_profiles/ (copied to profiles/ by hand).
+# configuration, SQ counters of the wide kernel.  Summaries land in gpurun_out/r2_profiles/ (the files to copy into profiles/).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r2_profiles; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -18,4 +18,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $O/pmc_wide_$c -o w -- python $R/tools/pipe_only.py 10000000 256 12 > /dev/null 2> $O/pmc_wide_$c.err
   python $R/tools/rocpd_pmc.py $O/pmc_wide_$c/w_results.db scan_wide 1000 > $O/pmc_wide_$c.jsonl
 done
-rm -rf $O/*/w_results.db.tmp; du -sh $O; ls $O
+python $R/tools/summarise_profiles.py $O > $O/summarise.log 2>&1
+rm -rf $O/*/w_results.db.tmp $O/*/*.db; du -sh $O; ls $O; cat $O/summarise.log
