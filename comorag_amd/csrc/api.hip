@@ -85,13 +85,16 @@ struct Workspace {
     DevBuf d_pack;
     int* flag_ptr = nullptr;     // the non-finite-query flag the kernels set: flag.p, or the head of d_pack for the host API
     void* h_pin = nullptr;
+    void* h_pin_dev = nullptr;   // the same buffer as the device sees it (mapped, fine-grained)
     size_t h_pin_cap = 0;
     hipError_t ensure_pin(size_t need) {
         if (need <= h_pin_cap) return hipSuccess;
-        if (h_pin) { hipError_t e = hipHostFree(h_pin); if (e != hipSuccess) return e; h_pin = nullptr; h_pin_cap = 0; }
+        if (h_pin) { hipError_t e = hipHostFree(h_pin); if (e != hipSuccess) return e; h_pin = nullptr; h_pin_dev = nullptr; h_pin_cap = 0; }
         const size_t want = std::max(need, h_pin_cap * 2);
         hipError_t e = hipHostMalloc(&h_pin, want, hipHostMallocDefault);
         if (e != hipSuccess) return e;
+        e = hipHostGetDevicePointer(&h_pin_dev, h_pin, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h_pin); h_pin = nullptr; return e; }
         h_pin_cap = want;
         return hipSuccess;
     }
@@ -101,7 +104,7 @@ struct Workspace {
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
         d_pack.release();
         if (h_pin) (void)hipHostFree(h_pin);
-        h_pin = nullptr; h_pin_cap = 0;
+        h_pin = nullptr; h_pin_dev = nullptr; h_pin_cap = 0;
         if (own_stream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -943,8 +946,7 @@ static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t
         const size_t o_q = (out_bytes + 255) & ~(size_t)255;
         HIP_TRY(ws->ensure_pin(o_q + q_bytes));
         char* h = (char*)ws->h_pin;
-        char* d = nullptr;
-        HIP_TRY(hipHostGetDevicePointer((void**)&d, h, 0));
+        char* d = (char*)ws->h_pin_dev;
         memcpy(h + o_q, q, q_bytes);
         memset(h, 0, 8);
         int* const dev_flag = ws->flag_ptr;
