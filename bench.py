@@ -29,6 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HIP events bracket every PROFILE_EVERY-th main scan of the timed region: the two event packets cost ~25 us on the scan stream
+# (9 % of a 1 M-row step), so timing every launch would slow what `value` reports; tools/pipe_only.py times none at all
+PROFILE_EVERY = 4
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: measured float4 copy
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # same guide: dense bf16 peak (spec)
 
@@ -79,12 +82,12 @@ def build_shard(torch, args, rows, rank, world, device, host=None, timing=False)
     return sh
 
 
-def run_steps(torch, dist, sh, q, k, steps, warmup, world, device):
+def run_steps(torch, dist, sh, q, k, steps, warmup, world, device, every=PROFILE_EVERY):
     for i in range(warmup):
         sh.search_pipelined(q, k, i & 1)["done"].synchronize()
     torch.cuda.synchronize(device)
     sh.times = []
-    sh.local.profile(True)
+    sh.local.profile(every)       # HIP events around every `every`-th main scan of the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -326,7 +329,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": head["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac_of_8TBps"],
                      "frac_of_achievable_6290": head["hbm_GBps"] / HBM_ACHIEVABLE_GBS, "traffic": None,
                      "kernel": "scan_kernel (fused MFMA scan + top-k)", "kernel_ms": head["kernel_ms"],
-                     "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"],
+                     "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"], "timed_every": PROFILE_EVERY,
                      "rows_per_gpu": len(sh)},
         "verified": {"last_pipelined_batch_equals_synchronous_search": same},
     }

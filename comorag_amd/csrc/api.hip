@@ -77,7 +77,7 @@ struct DevBuf {
 struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    DevBuf qfrag, lists, cnt, mm, flag, tau, s_lists, s_cnt, s_mm;
+    DevBuf qfrag, lists, cnt, mm, flag, tau, s_lists, s_cnt, s_mm, arrive;
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
     // synchronous search: queries in, (ids | scores | min | max | non-finite flag) out through ONE pinned host buffer and
@@ -100,7 +100,7 @@ struct Workspace {
     }
     void release() {
         qfrag.release(); lists.release(); cnt.release(); mm.release(); flag.release(); tau.release();
-        s_lists.release(); s_cnt.release(); s_mm.release();
+        s_lists.release(); s_cnt.release(); s_mm.release(); arrive.release();
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
         d_pack.release();
         if (h_pin) (void)hipHostFree(h_pin);
@@ -137,6 +137,8 @@ struct cmr_index {
     // profiling
     std::mutex prof_mu;
     bool prof_on = false;
+    int prof_every = 1;          // time every prof_every-th main scan (two event packets on the scan stream cost ~25 us between scans)
+    unsigned prof_seq = 0;
     std::vector<ProfEvent> prof_events;
     double prof_bytes = 0.0;
     // knobs (env)
@@ -147,6 +149,7 @@ struct cmr_index {
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch path for corpora of <= 1024 rows
     int single_level = 1;    // CMR_SAMPLE_SINGLE=0: small batches on mid-size corpora sample in two levels like everything else
+    int tiny_multi = 1;      // CMR_TINY_MULTI=0: the tiny path always runs as one workgroup
     int zero_copy = 1;       // CMR_ZERO_COPY=0: the synchronous host API copies queries / results instead of mapping them
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
@@ -448,7 +451,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     bool prof = false;
     {
         std::lock_guard<std::mutex> pg(idx->prof_mu);
-        prof = idx->prof_on;
+        prof = idx->prof_on && (idx->prof_seq++ % (unsigned)idx->prof_every) == 0;
     }
     if (prof) {
         HIP_TRY(hipEventCreate(&pe.a));
@@ -483,8 +486,12 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         if (!idx->no_tiny && !min_score && npanels <= 32 && nq <= 16 && idx->n > 0) {
             { int rc_ = arm_flag(ws, ws->stream); if (rc_) return rc_; }
             HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels)));
+            if (!ws->arrive.p) {          // arrival counter of the multi-workgroup tiny search: zeroed once, re-armed by the kernel
+                HIP_TRY(ws->arrive.ensure(sizeof(int)));
+                HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), ws->stream));
+            }
             HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, (float*)ws->d_out.p,
-                                           ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, ws->stream));
+                                           ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, ws->stream));
             return CMR_OK;
         }
     }
@@ -728,6 +735,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
     idx->zero_copy = env_int("CMR_ZERO_COPY", 1);
+    idx->tiny_multi = env_int("CMR_TINY_MULTI", 1);
     idx->single_level = env_int("CMR_SAMPLE_SINGLE", 1);
     idx->no_tiny = env_int("CMR_SCAN_NO_TINY", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
@@ -1190,6 +1198,8 @@ int32_t cmr_profile_enable(cmr_index_t* idx, int32_t on) {
     if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
     std::lock_guard<std::mutex> g(idx->prof_mu);
     idx->prof_on = on != 0;
+    idx->prof_every = on > 1 ? on : 1;
+    idx->prof_seq = 0;
     return CMR_OK;
 }
 

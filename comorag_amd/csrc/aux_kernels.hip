@@ -1,6 +1,8 @@
 // Small kernels around the corpus scan: operand packing (queries, appended rows), candidate
 // merges, exact re-score, row gather and the encoder tail (masked mean-pool + L2 normalise).
 // All are launch-latency or HBM bound; none uses MFMA.
+#include <algorithm>
+
 #include "cmr_device.h"
 #include "cmr_kernels.h"
 
@@ -393,12 +395,19 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 // check), the MFMA scan (wave w takes panels w, w+8, ..; same block order, hence the same fp32 chains and bit-identical
 // scores, as scan_kernel), per-query selection (wave w takes queries w, w+8, ..: k rounds of arg-max over the <= 16 keys
 // a lane holds) and min / max.  The general path costs 3 launches there (pack, scan, merge) on 108-126 us per call.
+__device__ __forceinline__ u64 tiny_readlane(u64 v, int l) {      // l wave-uniform
+    return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+
 template <int DT>
 __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict__ corpus, const float* __restrict__ q, int nq, int dim, int ks_total,
                                                           int nrows, int npanels, int k, long long id_base, float* __restrict__ scratch,
                                                           int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
-                                                          float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag, int stage_raw) {
+                                                          float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag, int stage_raw,
+                                                          int* __restrict__ arrive) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    __shared__ int ticket;
+    __shared__ u64 tiny_stage[8][64];       // per wave: the selection's surviving keys
     uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64], then (stage_raw) the fp32 queries [nq][dim]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqt = (nq + 31) / 32;
@@ -429,7 +438,10 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
     __syncthreads();
     const int ld = npanels * CMR_PANEL_ROWS;
     const v4u* qv = reinterpret_cast<const v4u*>(qf);
-    for (int p = wave; p < npanels; p += 8) {
+    // More than 8 panels: up to four workgroups share the scan (a wave streams its panels one after the other, 3.6 us
+    // each: 14 us for the four panels a wave had at 1000 rows) and the LAST one to arrive does the selection.
+    const int nwg = gridDim.x;
+    for (int p = blockIdx.x * 8 + wave; p < npanels; p += 8 * nwg) {
         for (int t = 0; t < nqt; ++t) {
             f32x16 acc;
 #pragma unroll
@@ -449,9 +461,19 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (nwg > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // my scores are in L2 before my ticket is
+        __syncthreads();
+        if (tid == 0) ticket = atomicAdd(arrive, 1);
+        __syncthreads();
+        if (ticket != nwg - 1) return;
+        if (tid == 0) *arrive = 0;                                  // everybody has arrived: re-armed for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other workgroups' scores, not stale L1 lines
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     for (int qi = wave; qi < nq; qi += 8) {
         u64 key[16];
         float mn = __builtin_inff(), mx = -__builtin_inff();
@@ -468,7 +490,51 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
         if (lane == 0) { if (out_min) out_min[qi] = mn; if (out_max) out_max[qi] = mx; }
-        for (int round = 0; round < k; ++round) {
+        // Selection without rounds (k <= 64): k rounds of "wave-wide arg-max, remove" cost ~1300 cycles each — 13 us at
+        // k = 20, a quarter of the whole call.  Instead: the k-th largest of the 64 per-lane maxima T is a lower bound of
+        // the k-th best key (k lanes hold a key >= T), so only keys >= T can win; those survivors (k .. a few dozen) are
+        // compacted into one key per lane and ranked by counting — lane l's key goes to output position rank(l).  All
+        // cross-lane traffic is v_readlane (keys are unique, 0 = empty).  More than 64 survivors (many lanes whose second
+        // best also beats T) or k > 64: the rounds below.
+        bool ranked = false;
+        if (k <= 64) {
+            u64 best = 0ull;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
+            int rk = 0;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) rk += tiny_readlane(best, l) > best ? 1 : 0;
+            const u64 has = __ballot(best != 0ull && rk == k - 1);
+            const u64 T = has ? tiny_readlane(best, __ffsll((long long)has) - 1) : 0ull;      // fewer than k lanes hold a key: everything survives
+            u64* stage = tiny_stage[wave];
+            int S = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool sv = key[j] != 0ull && key[j] >= T;
+                const u64 m = __ballot(sv);
+                const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (sv && slot < 64) stage[slot] = key[j];
+                S += __popcll(m);
+            }
+            if (S <= 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const u64 mine = lane < S ? stage[lane] : 0ull;
+                int r = 0;
+                for (int l = 0; l < S; ++l) r += tiny_readlane(mine, l) > mine ? 1 : 0;
+                if (lane < S && r < k) {
+                    out_ids[(size_t)qi * k + r] = (int64_t)cmr_key_row(mine) + id_base;
+                    out_scores[(size_t)qi * k + r] = cmr_key_score(mine);
+                }
+                if (lane >= S && lane < k) {            // fewer than k rows with a score: the tail is empty
+                    out_ids[(size_t)qi * k + lane] = -1;
+                    out_scores[(size_t)qi * k + lane] = -__builtin_inff();
+                }
+                ranked = true;
+            }
+        }
+        for (int round = 0; round < (ranked ? 0 : k); ++round) {
             u64 best = 0ull;
 #pragma unroll
             for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
@@ -490,7 +556,8 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
 size_t cmr_tiny_scratch_bytes(int nq, int npanels) { return (size_t)nq * npanels * CMR_PANEL_ROWS * sizeof(float); }
 
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
-                                  float* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, hipStream_t s) {
+                                  float* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
+                                  hipStream_t s) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     const int nqt = (nq + 31) / 32;
@@ -499,12 +566,13 @@ hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q,
     const int stage_raw = lds + (size_t)nq * dim * 4 <= 160 * 1024 ? 1 : 0;      // fp32 at 1024-d: the operands alone take 128 KiB
     if (stage_raw) lds += (size_t)nq * dim * 4;
     const v4u* c = reinterpret_cast<const v4u*>(corpus);
+    const int nwg = (arrive && npanels > 8) ? std::min(4, (npanels + 7) / 8) : 1;      // arrive: a zeroed int the launches of one stream share
 #define TS(DT)                                                                                                                       \
     {                                                                                                                                \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                               \
-        hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(1), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scratch, out_ids, \
-                           out_scores, out_min, out_max, flag, stage_raw);                                                           \
+        hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scratch, out_ids, \
+                           out_scores, out_min, out_max, flag, stage_raw, arrive);                                                   \
     }
     switch (dtype) {
         case CMR_DT_BF16: TS(CMR_DT_BF16) break;

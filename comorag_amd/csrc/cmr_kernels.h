@@ -70,7 +70,8 @@ hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int n
 // whole search of a tiny corpus (<= 32 panels, nq <= 16, k <= 128) in one single-workgroup launch
 size_t cmr_tiny_scratch_bytes(int nq, int npanels);
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
-                                  float* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, hipStream_t s);
+                                  float* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
+                                  hipStream_t s);
 // per-row top-k (k <= 4096) of a materialised score matrix [nq, ld]
 hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq, int k, long long id_base,
                                 int64_t* out_ids, float* out_scores, float* out_min, float* out_max, hipStream_t s);

@@ -231,8 +231,9 @@ class DenseIndex:
         return out
 
     # -- measurement
-    def profile(self, on: bool) -> None:
-        L.check(L.lib().cmr_profile_enable(self._h, 1 if on else 0))
+    def profile(self, on) -> None:
+        """HIP-event timing of the main scans: True / 1 = every scan, N > 1 = every N-th scan, False / 0 = off."""
+        L.check(L.lib().cmr_profile_enable(self._h, int(on)))
 
     def profile_collect(self) -> dict:
         n, ms, b = C.c_int64(0), C.c_double(0), C.c_double(0)

@@ -58,7 +58,8 @@ def test_small_shapes(dtype, n):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16", "f32"])
-@pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (6, 1, 5), (6, 3, 20), (33, 8, 20), (1000, 1, 20), (1024, 16, 20), (1024, 9, 128), (700, 16, 7)])
+@pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (6, 1, 5), (6, 3, 20), (33, 8, 20), (1000, 1, 20), (1024, 16, 20), (1024, 9, 128), (700, 16, 7),
+                                    (257, 2, 20), (513, 1, 20)])
 def test_tiny_single_launch_path_equals_general_path(dtype, n, nq, k):
     """<= 1024 rows: one single-workgroup launch (tiny_search_kernel) — must equal the oracle and, bit for bit, the
     general pack / scan / merge path (CMR_SCAN_NO_TINY=1)."""
@@ -68,6 +69,9 @@ def test_tiny_single_launch_path_equals_general_path(dtype, n, nq, k):
     a_ids, a_sc = _check(dtype, X, Q, k)
     b_ids, b_sc = _check(dtype, X, Q, k, env={"CMR_SCAN_NO_TINY": "1"})
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+    if n > 256:                                                    # more than 8 panels: up to four workgroups scan, the last one to arrive selects
+        c_ids, c_sc = _check(dtype, X, Q, k, env={"CMR_TINY_MULTI": "0"})
+        assert np.array_equal(a_ids, c_ids) and np.array_equal(a_sc, c_sc)
 
 
 @pytest.mark.parametrize("n,nq,k", [(6, 1, 5), (1000, 3, 20), (5000, 1, 20), (140_000, 1, 20), (140_000, 8, 20), (20_000, 64, 20), (3000, 2, 100)])
