@@ -149,7 +149,8 @@ struct cmr_index {
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
     int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch path for corpora of <= 1024 rows
     int single_level = 1;    // CMR_SAMPLE_SINGLE=0: small batches on mid-size corpora sample in two levels like everything else
-    int tiny_multi = 1;      // CMR_TINY_MULTI=0: the tiny path always runs as one workgroup
+    int tiny_multi = 1;      // CMR_TINY_MULTI=0: the single-launch path always runs as one workgroup (<= 1024 rows only)
+    int no_small = 0;        // CMR_SCAN_NO_SMALL=1: corpora of 1025 rows .. 64 K rows take the general path also for few queries
     int zero_copy = 1;       // CMR_ZERO_COPY=0: the synchronous host API copies queries / results instead of mapping them
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
@@ -474,6 +475,18 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     return CMR_OK;
 }
 
+// 0: the general pack / [sample] / scan / merge chain; 1: single launch, <= 1024 rows; 2: single launch, hierarchical
+// selection (<= 16 queries, k <= 64, up to 64 K rows while workgroups x k <= 1024) — see tiny_search_kernel
+int small_path_kind(const cmr_index* idx, int nq, int k, bool threshold_search) {
+    if (idx->no_tiny || threshold_search || idx->n <= 0 || nq > 16 || k > CMR_MAX_K) return 0;
+    const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+    if (npanels > 2048) return 0;
+    const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
+    if ((size_t)ks * 1024 > 160 * 1024) return 0;                    // the packed operands of one query tile must fit LDS
+    const int kind = cmr_tiny_kind(nq, (int)npanels, k, idx->tiny_multi);
+    return (kind == 2 && idx->no_small) ? 0 : kind;
+}
+
 int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev,
                    float* min_dev, float* max_dev, const float* min_score = nullptr) {
     if (k > CMR_MAX_K) {
@@ -481,19 +494,17 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         return search_large_k_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
     }
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
-    {   // tiny corpus: one single-workgroup launch does packing, scan, selection and min/max
+    if (small_path_kind(idx, nq, k, min_score != nullptr)) {   // small corpus, few queries: ONE launch does packing, scan, selection and min/max
         const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-        if (!idx->no_tiny && !min_score && npanels <= 32 && nq <= 16 && idx->n > 0) {
-            { int rc_ = arm_flag(ws, ws->stream); if (rc_) return rc_; }
-            HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels)));
-            if (!ws->arrive.p) {          // arrival counter of the multi-workgroup tiny search: zeroed once, re-armed by the kernel
-                HIP_TRY(ws->arrive.ensure(sizeof(int)));
-                HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), ws->stream));
-            }
-            HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, (float*)ws->d_out.p,
-                                           ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, ws->stream));
-            return CMR_OK;
+        { int rc_ = arm_flag(ws, ws->stream); if (rc_) return rc_; }
+        HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels, k, idx->tiny_multi)));
+        if (!ws->arrive.p) {          // arrival counter of the multi-workgroup search: zeroed once, re-armed by the kernel
+            HIP_TRY(ws->arrive.ensure(sizeof(int)));
+            HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), ws->stream));
         }
+        HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, ws->d_out.p,
+                                       ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, ws->stream));
+        return CMR_OK;
     }
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
@@ -736,6 +747,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
     idx->zero_copy = env_int("CMR_ZERO_COPY", 1);
     idx->tiny_multi = env_int("CMR_TINY_MULTI", 1);
+    idx->no_small = env_int("CMR_SCAN_NO_SMALL", 0);
     idx->single_level = env_int("CMR_SAMPLE_SINGLE", 1);
     idx->no_tiny = env_int("CMR_SCAN_NO_TINY", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
@@ -946,6 +958,9 @@ static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t
                  out_bytes = o_max + (size_t)nq * 4, q_bytes = (size_t)nq * idx->dim * 4;
     const char* hp = nullptr;
     if (idx->zero_copy && k <= CMR_MAX_K && q_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax) {
+        // (the hierarchical single-launch path packs the queries in up to 64 workgroups: they read a device copy, not
+        // 64 times across the link)
+        const bool map_in = small_path_kind(idx, nq, k, min_score != nullptr) != 2;
         // Small calls (what ComoRAG issues: one query, a few hundred rows) are all latency.  A copy each way costs two more
         // submissions in front of / behind the kernels (36 us per call at 6 rows, of which the search itself is ~8); so
         // there are none: queries, results and the non-finite flag live in ONE pinned, device-mapped host buffer
@@ -957,9 +972,15 @@ static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t
         char* d = (char*)ws->h_pin_dev;
         memcpy(h + o_q, q, q_bytes);
         memset(h, 0, 8);
+        const float* q_in = (const float*)(d + o_q);
+        if (!map_in) {
+            HIP_TRY(ws->d_q.ensure(q_bytes));
+            HIP_TRY(hipMemcpyAsync(ws->d_q.p, h + o_q, q_bytes, hipMemcpyHostToDevice, s));
+            q_in = (const float*)ws->d_q.p;
+        }
         int* const dev_flag = ws->flag_ptr;
         ws->flag_ptr = (int*)d;
-        rc = search_enqueue(idx, ws, (const float*)(d + o_q), nq, k, (int64_t*)(d + o_ids), (float*)(d + o_sc), (float*)(d + o_min), (float*)(d + o_max), min_score);
+        rc = search_enqueue(idx, ws, q_in, nq, k, (int64_t*)(d + o_ids), (float*)(d + o_sc), (float*)(d + o_min), (float*)(d + o_max), min_score);
         ws->flag_ptr = dev_flag;
         if (rc) { (void)hipStreamSynchronize(s); return rc; }
         HIP_TRY(hipStreamSynchronize(s));

@@ -390,13 +390,100 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 }
 
 // ------------------------------------------------------------------------------------------
-// Tiny corpora (<= 32 panels = 1024 rows, <= 16 queries; ComoRAG's per-question calls see 6 chunks to a few hundred facts, one query at a
-// time): the whole search in ONE launch of ONE workgroup — query packing (fp32 -> MFMA B-operands in LDS, non-finite
-// check), the MFMA scan (wave w takes panels w, w+8, ..; same block order, hence the same fp32 chains and bit-identical
-// scores, as scan_kernel), per-query selection (wave w takes queries w, w+8, ..: k rounds of arg-max over the <= 16 keys
-// a lane holds) and min / max.  The general path costs 3 launches there (pack, scan, merge) on 108-126 us per call.
+// Small corpora, few queries (<= 16; ComoRAG's per-question calls see 6 chunks to a few thousand facts / entities, one
+// query at a time): the whole search in ONE launch — query packing (fp32 -> MFMA B-operands in LDS, non-finite check),
+// the MFMA scan (same block order, hence the same fp32 chains and bit-identical scores, as scan_kernel), selection and
+// min / max.  The general path is a chain of 3-5 dependent launches there (pack, [sample scan, merge,] scan, merge):
+// 84 us per call at 10 K rows of which the scans are 24.
+//   * <= 32 panels (1024 rows): up to four workgroups scan 8 panels each (a wave streams its panels one after the
+//     other, 3.6 us each), the LAST one to arrive — release fence, ticket from a self-re-arming counter, acquire fence —
+//     selects among all rows (one wave per query, <= 16 keys per lane).
+//   * more panels (HIER, up to 64 workgroups x 32 panels = 64 K rows as long as workgroups x k <= 1024): every workgroup
+//     also selects the k best of ITS rows per query and publishes them with its min / max; the last one to arrive
+//     selects among the workgroups' candidates.  The k best rows overall are among the k best of their workgroup, so the
+//     result is exact.
+// Selection by one wave over <= 16 keys per lane (0 = empty, keys unique), without rounds for k <= 64: k rounds of
+// "wave-wide arg-max, remove" cost ~1300 cycles each — 13 us at k = 20.  Instead the k-th largest of the 64 per-lane maxima
+// T is a lower bound of the k-th best key (k lanes hold a key >= T), so only keys >= T can win; those survivors (k .. a
+// few dozen) are compacted into one key per lane and ranked by counting — lane l's key goes to output position rank(l).
+// All cross-lane traffic is v_readlane.  More than 64 survivors (many lanes whose second best also beats T) or k > 64:
+// the rounds.  emit(rank, key) is called exactly once for every rank < k (key 0: no such row), by one lane.
 __device__ __forceinline__ u64 tiny_readlane(u64 v, int l) {      // l wave-uniform
     return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, l);
+}
+
+template <class Emit>
+__device__ __forceinline__ void tiny_select(u64 (&key)[16], int k, u64* stage, int lane, Emit emit) {
+    if (k <= 64) {
+        u64 best = 0ull;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
+        int rk = 0;
+#pragma unroll
+        for (int l = 0; l < 64; ++l) rk += tiny_readlane(best, l) > best ? 1 : 0;
+        const u64 has = __ballot(best != 0ull && rk == k - 1);
+        const u64 T = has ? tiny_readlane(best, __ffsll((long long)has) - 1) : 0ull;      // fewer than k lanes hold a key: everything survives
+        int S = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool sv = key[j] != 0ull && key[j] >= T;
+            const u64 m = __ballot(sv);
+            const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (sv && slot < 64) stage[slot] = key[j];
+            S += __popcll(m);
+        }
+        if (S <= 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const u64 mine = lane < S ? stage[lane] : 0ull;
+            int r = 0;
+            for (int l = 0; l < S; ++l) r += tiny_readlane(mine, l) > mine ? 1 : 0;
+            if (lane < S && r < k) emit(r, mine);
+            if (lane >= S && lane < k) emit(lane, 0ull);          // fewer than k rows with a score: the tail is empty
+            __builtin_amdgcn_wave_barrier();                         // the stage is reused by this wave's next query
+            return;
+        }
+    }
+    for (int round = 0; round < k; ++round) {
+        u64 best = 0ull;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
+        u64 wb = best;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
+        if (wb != 0ull && best == wb) {          // keys are unique: exactly one lane, one slot
+#pragma unroll
+            for (int j = 0; j < 16; ++j) key[j] = key[j] == wb ? 0ull : key[j];
+        }
+        if (lane == 0) emit(round, wb);
+    }
+}
+
+// geometry of the single-launch search: 0 = not applicable, 1 = flat (<= 32 panels), 2 = hierarchical
+struct TinyGeom { int kind, nwg, ppw; size_t off_cand, off_mm, bytes; };
+static TinyGeom tiny_geom(int nq, int npanels, int k, bool multi) {
+    TinyGeom g{0, 1, 32, 0, 0, 0};
+    if (nq > 16 || npanels <= 0 || k <= 0) return g;
+    const size_t scores = ((size_t)nq * npanels * CMR_PANEL_ROWS * sizeof(float) + 255) & ~(size_t)255;
+    if (npanels <= 32) {
+        g.kind = 1;
+        g.nwg = (multi && npanels > 8) ? (npanels + 7) / 8 : 1;
+        g.ppw = g.nwg == 1 ? 32 : 8;
+        g.bytes = scores;
+        return g;
+    }
+    if (!multi || k > 64 || npanels > 2048) return g;
+    const int maxwg = std::min(64, 1024 / k);
+    const int ppw = 8 * ((npanels + 8 * maxwg - 1) / (8 * maxwg));
+    if (ppw > 32) return g;
+    g.kind = 2;
+    g.ppw = ppw;
+    g.nwg = (npanels + ppw - 1) / ppw;
+    g.off_cand = scores;
+    g.off_mm = g.off_cand + (((size_t)g.nwg * nq * k * sizeof(u64) + 255) & ~(size_t)255);
+    g.bytes = g.off_mm + (size_t)g.nwg * nq * sizeof(float2);
+    return g;
 }
 
 template <int DT>
@@ -404,13 +491,14 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
                                                           int nrows, int npanels, int k, long long id_base, float* __restrict__ scratch,
                                                           int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                                           float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag, int stage_raw,
-                                                          int* __restrict__ arrive) {
+                                                          int* __restrict__ arrive, int ppw, u64* __restrict__ cand, float2* __restrict__ part_mm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     __shared__ int ticket;
     __shared__ u64 tiny_stage[8][64];       // per wave: the selection's surviving keys
     uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64], then (stage_raw) the fp32 queries [nq][dim]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqt = (nq + 31) / 32;
+    const bool hier = cand != nullptr;
     bool bad = false;
     // The synchronous host API maps the queries from pinned host memory (no copy in front of the launch): fetch them with
     // independent, unconditional loads — eight in flight per thread, one PCIe round trip for a single query — into LDS
@@ -438,10 +526,9 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
     __syncthreads();
     const int ld = npanels * CMR_PANEL_ROWS;
     const v4u* qv = reinterpret_cast<const v4u*>(qf);
-    // More than 8 panels: up to four workgroups share the scan (a wave streams its panels one after the other, 3.6 us
-    // each: 14 us for the four panels a wave had at 1000 rows) and the LAST one to arrive does the selection.
     const int nwg = gridDim.x;
-    for (int p = blockIdx.x * 8 + wave; p < npanels; p += 8 * nwg) {
+    const int p_lo = blockIdx.x * ppw, p_hi = p_lo + ppw < npanels ? p_lo + ppw : npanels;      // this workgroup's panels
+    for (int p = p_lo + wave; p < p_hi; p += 8) {
         for (int t = 0; t < nqt; ++t) {
             f32x16 acc;
 #pragma unroll
@@ -461,14 +548,40 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
             }
         }
     }
+    u64* stage = tiny_stage[wave];
+    if (hier) {         // the k best of this workgroup's rows, per query
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int row_lo = p_lo * CMR_PANEL_ROWS, nloc = (p_hi - p_lo) * CMR_PANEL_ROWS;      // <= 1024 rows
+        for (int qi = wave; qi < nq; qi += 8) {
+            u64 key[16];
+            float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int lr = lane + 64 * j, row = row_lo + lr;
+                key[j] = 0ull;
+                if (lr < nloc && row < nrows) {
+                    const float v = scratch[(size_t)qi * ld + row];
+                    mn = fminf(mn, v); mx = fmaxf(mx, v);
+                    if (v == v) key[j] = cmr_make_key(v, (unsigned)row);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+            if (lane == 0) part_mm[(size_t)blockIdx.x * nq + qi] = make_float2(mn, mx);
+            u64* dst = cand + ((size_t)blockIdx.x * nq + qi) * k;
+            tiny_select(key, k, stage, lane, [&](int r, u64 kk) { dst[r] = kk; });
+        }
+    }
     if (nwg > 1) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // my scores are in L2 before my ticket is
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // my scores / candidates are in L2 before my ticket is
         __syncthreads();
         if (tid == 0) ticket = atomicAdd(arrive, 1);
         __syncthreads();
         if (ticket != nwg - 1) return;
         if (tid == 0) *arrive = 0;                                  // everybody has arrived: re-armed for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other workgroups' scores, not stale L1 lines
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // the other workgroups' stores, not stale L1 lines
     } else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
@@ -477,102 +590,63 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
     for (int qi = wave; qi < nq; qi += 8) {
         u64 key[16];
         float mn = __builtin_inff(), mx = -__builtin_inff();
+        if (!hier) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = lane + 64 * j;
-            key[j] = 0ull;
-            if (row < nrows) {
-                const float v = scratch[(size_t)qi * ld + row];
-                mn = fminf(mn, v); mx = fmaxf(mx, v);
-                if (v == v) key[j] = cmr_make_key(v, (unsigned)row);
+            for (int j = 0; j < 16; ++j) {
+                const int row = lane + 64 * j;
+                key[j] = 0ull;
+                if (row < nrows) {
+                    const float v = scratch[(size_t)qi * ld + row];
+                    mn = fminf(mn, v); mx = fmaxf(mx, v);
+                    if (v == v) key[j] = cmr_make_key(v, (unsigned)row);
+                }
+            }
+        } else {
+            const int ncand = nwg * k;                              // <= 1024
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = lane + 64 * j;
+                key[j] = i < ncand ? cand[((size_t)(i / k) * nq + qi) * k + i % k] : 0ull;
+            }
+            for (int b = lane; b < nwg; b += 64) {
+                const float2 v = part_mm[(size_t)b * nq + qi];
+                mn = fminf(mn, v.x); mx = fmaxf(mx, v.y);
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
         if (lane == 0) { if (out_min) out_min[qi] = mn; if (out_max) out_max[qi] = mx; }
-        // Selection without rounds (k <= 64): k rounds of "wave-wide arg-max, remove" cost ~1300 cycles each — 13 us at
-        // k = 20, a quarter of the whole call.  Instead: the k-th largest of the 64 per-lane maxima T is a lower bound of
-        // the k-th best key (k lanes hold a key >= T), so only keys >= T can win; those survivors (k .. a few dozen) are
-        // compacted into one key per lane and ranked by counting — lane l's key goes to output position rank(l).  All
-        // cross-lane traffic is v_readlane (keys are unique, 0 = empty).  More than 64 survivors (many lanes whose second
-        // best also beats T) or k > 64: the rounds below.
-        bool ranked = false;
-        if (k <= 64) {
-            u64 best = 0ull;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
-            int rk = 0;
-#pragma unroll
-            for (int l = 0; l < 64; ++l) rk += tiny_readlane(best, l) > best ? 1 : 0;
-            const u64 has = __ballot(best != 0ull && rk == k - 1);
-            const u64 T = has ? tiny_readlane(best, __ffsll((long long)has) - 1) : 0ull;      // fewer than k lanes hold a key: everything survives
-            u64* stage = tiny_stage[wave];
-            int S = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool sv = key[j] != 0ull && key[j] >= T;
-                const u64 m = __ballot(sv);
-                const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (sv && slot < 64) stage[slot] = key[j];
-                S += __popcll(m);
-            }
-            if (S <= 64) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const u64 mine = lane < S ? stage[lane] : 0ull;
-                int r = 0;
-                for (int l = 0; l < S; ++l) r += tiny_readlane(mine, l) > mine ? 1 : 0;
-                if (lane < S && r < k) {
-                    out_ids[(size_t)qi * k + r] = (int64_t)cmr_key_row(mine) + id_base;
-                    out_scores[(size_t)qi * k + r] = cmr_key_score(mine);
-                }
-                if (lane >= S && lane < k) {            // fewer than k rows with a score: the tail is empty
-                    out_ids[(size_t)qi * k + lane] = -1;
-                    out_scores[(size_t)qi * k + lane] = -__builtin_inff();
-                }
-                ranked = true;
-            }
-        }
-        for (int round = 0; round < (ranked ? 0 : k); ++round) {
-            u64 best = 0ull;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
-            u64 wb = best;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
-            if (wb != 0ull && best == wb) {          // keys are unique: exactly one lane, one slot
-#pragma unroll
-                for (int j = 0; j < 16; ++j) key[j] = key[j] == wb ? 0ull : key[j];
-            }
-            if (lane == 0) {
-                out_ids[(size_t)qi * k + round] = wb ? (int64_t)cmr_key_row(wb) + id_base : -1;
-                out_scores[(size_t)qi * k + round] = wb ? cmr_key_score(wb) : -__builtin_inff();
-            }
-        }
+        tiny_select(key, k, stage, lane, [&](int r, u64 kk) {
+            out_ids[(size_t)qi * k + r] = kk ? (int64_t)cmr_key_row(kk) + id_base : -1;
+            out_scores[(size_t)qi * k + r] = kk ? cmr_key_score(kk) : -__builtin_inff();
+        });
     }
 }
 
-size_t cmr_tiny_scratch_bytes(int nq, int npanels) { return (size_t)nq * npanels * CMR_PANEL_ROWS * sizeof(float); }
+int cmr_tiny_kind(int nq, int npanels, int k, int multi) { return tiny_geom(nq, npanels, k, multi != 0).kind; }
+size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi) { return tiny_geom(nq, npanels, k, multi != 0).bytes; }
 
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
-                                  float* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
+                                  void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
                                   hipStream_t s) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     const int nqt = (nq + 31) / 32;
     size_t lds = (size_t)nqt * ks * 1024;
-    if (npanels > 32 || nq > 16 || lds > 160 * 1024) return hipErrorInvalidValue;
+    const TinyGeom g = tiny_geom(nq, npanels, k, arrive != nullptr);
+    if (!g.kind || lds > 160 * 1024) return hipErrorInvalidValue;
     const int stage_raw = lds + (size_t)nq * dim * 4 <= 160 * 1024 ? 1 : 0;      // fp32 at 1024-d: the operands alone take 128 KiB
     if (stage_raw) lds += (size_t)nq * dim * 4;
     const v4u* c = reinterpret_cast<const v4u*>(corpus);
-    const int nwg = (arrive && npanels > 8) ? std::min(4, (npanels + 7) / 8) : 1;      // arrive: a zeroed int the launches of one stream share
+    float* scores = reinterpret_cast<float*>(scratch);
+    u64* cand = g.kind == 2 ? reinterpret_cast<u64*>(reinterpret_cast<char*>(scratch) + g.off_cand) : nullptr;
+    float2* pmm = g.kind == 2 ? reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + g.off_mm) : nullptr;
 #define TS(DT)                                                                                                                       \
     {                                                                                                                                \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                               \
-        hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scratch, out_ids, \
-                           out_scores, out_min, out_max, flag, stage_raw, arrive);                                                   \
+        hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(g.nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scores, out_ids, \
+                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm);                                 \
     }
     switch (dtype) {
         case CMR_DT_BF16: TS(CMR_DT_BF16) break;

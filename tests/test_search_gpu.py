@@ -74,6 +74,23 @@ def test_tiny_single_launch_path_equals_general_path(dtype, n, nq, k):
         assert np.array_equal(a_ids, c_ids) and np.array_equal(a_sc, c_sc)
 
 
+@pytest.mark.parametrize("dtype,n,d,nq,k", [("bf16", 1025, 768, 1, 20), ("bf16", 3000, 768, 1, 20), ("bf16", 10_000, 768, 1, 20), ("f16", 10_000, 768, 16, 20),
+                                            ("bf16", 13_057, 128, 5, 20), ("bf16", 13_058, 128, 5, 21), ("f32", 20_000, 100, 3, 5), ("bf16", 40_000, 256, 2, 20),
+                                            ("bf16", 65_536, 64, 1, 16), ("bf16", 65_537, 64, 1, 16), ("bf16", 30_000, 64, 9, 64), ("bf16", 8_000, 64, 2, 65),
+                                            ("f32", 50_000, 1024, 1, 20), ("bf16", 2_000, 768, 1, 1)])
+def test_small_corpus_single_launch_hierarchical_selection(dtype, n, d, nq, k):
+    """1025 rows .. 64 K rows, <= 16 queries, k <= 64: ONE launch — every workgroup scans its panels and selects the k best of
+    its rows, the last workgroup to arrive selects among the workgroups' candidates (tiny_search_kernel).  Must equal the
+    oracle and, bit for bit, the general pack / sample / scan / merge chain (CMR_SCAN_NO_SMALL=1); sizes just past the
+    limits (65 537 rows, k = 65, workgroups x k > 1024) take the general chain anyway."""
+    X, Q = _mk(n, d, nq, seed=n % 997 + nq + k)
+    X[n - 1] = X[5]; X[n // 2] = X[5]; X[min(n - 1, 300)] = X[5]; Q[0] = X[5]      # one row four times: ties across workgroups and the last panel
+    a_ids, a_sc = _check(dtype, X, Q, k)
+    b_ids, b_sc = _check(dtype, X, Q, k, env={"CMR_SCAN_NO_SMALL": "1"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+    assert sorted(a_ids[0][:4].tolist()) == sorted({5, min(n - 1, 300), n // 2, n - 1}) or k < 4
+
+
 @pytest.mark.parametrize("n,nq,k", [(6, 1, 5), (1000, 3, 20), (5000, 1, 20), (140_000, 1, 20), (140_000, 8, 20), (20_000, 64, 20), (3000, 2, 100)])
 def test_zero_copy_host_api_equals_copy_path(n, nq, k):
     """The synchronous host API maps queries / results / the non-finite flag from pinned host memory (no copies around the
