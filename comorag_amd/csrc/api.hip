@@ -150,6 +150,7 @@ struct cmr_index {
     int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch path for corpora of <= 1024 rows
     int single_level = 1;    // CMR_SAMPLE_SINGLE=0: small batches on mid-size corpora sample in two levels like everything else
     int tiny_multi = 1;      // CMR_TINY_MULTI=0: the single-launch path always runs as one workgroup (<= 1024 rows only)
+    int small_max_panels = 6144;   // CMR_SMALL_MAX_PANELS: largest corpus (in 32-row panels) the single-launch path takes
     int no_small = 0;        // CMR_SCAN_NO_SMALL=1: corpora of 1025 rows .. 64 K rows take the general path also for few queries
     int zero_copy = 1;       // CMR_ZERO_COPY=0: the synchronous host API copies queries / results instead of mapping them
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
@@ -480,10 +481,10 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
 int small_path_kind(const cmr_index* idx, int nq, int k, bool threshold_search) {
     if (idx->no_tiny || threshold_search || idx->n <= 0 || nq > 16 || k > CMR_MAX_K) return 0;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
-    if (npanels > 2048) return 0;
+    if (npanels > idx->small_max_panels) return 0;
     const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
-    if ((size_t)ks * 1024 > 160 * 1024) return 0;                    // the packed operands of one query tile must fit LDS
-    const int kind = cmr_tiny_kind(nq, (int)npanels, k, idx->tiny_multi);
+    if ((size_t)ks * 1024 > 147 * 1024) return 0;                    // the packed operands of one query tile (+ 13 KiB of static LDS) must fit
+    const int kind = cmr_tiny_kind(nq, (int)npanels, k, idx->tiny_multi, idx->small_max_panels);
     return (kind == 2 && idx->no_small) ? 0 : kind;
 }
 
@@ -497,13 +498,13 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
     if (small_path_kind(idx, nq, k, min_score != nullptr)) {   // small corpus, few queries: ONE launch does packing, scan, selection and min/max
         const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
         { int rc_ = arm_flag(ws, ws->stream); if (rc_) return rc_; }
-        HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels, k, idx->tiny_multi)));
+        HIP_TRY(ws->d_out.ensure(cmr_tiny_scratch_bytes(nq, (int)npanels, k, idx->tiny_multi, idx->small_max_panels)));
         if (!ws->arrive.p) {          // arrival counter of the multi-workgroup search: zeroed once, re-armed by the kernel
             HIP_TRY(ws->arrive.ensure(sizeof(int)));
             HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), ws->stream));
         }
         HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, ws->d_out.p,
-                                       ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, ws->stream));
+                                       ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, idx->small_max_panels, ws->stream));
         return CMR_OK;
     }
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
@@ -748,6 +749,7 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->zero_copy = env_int("CMR_ZERO_COPY", 1);
     idx->tiny_multi = env_int("CMR_TINY_MULTI", 1);
     idx->no_small = env_int("CMR_SCAN_NO_SMALL", 0);
+    idx->small_max_panels = env_int("CMR_SMALL_MAX_PANELS", 6144);
     idx->single_level = env_int("CMR_SAMPLE_SINGLE", 1);
     idx->no_tiny = env_int("CMR_SCAN_NO_TINY", 0);
     idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);

@@ -460,9 +460,34 @@ __device__ __forceinline__ void tiny_select(u64 (&key)[16], int k, u64* stage, i
     }
 }
 
+// The same selection over a STREAM of n keys (fetch(i), 0 beyond n): one chunk of <= 1024 keys, or — k <= 64 — chunks of
+// 960 with the running k best carried along in the wave's LDS row (slot 15 of lanes 0 .. k-1).
+template <class Fetch, class Emit>
+__device__ __forceinline__ void tiny_select_stream(int n, int k, u64* stage, u64* carry, int lane, Fetch fetch, Emit emit) {
+    u64 key[16];
+    if (n <= 1024 || k > 64) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) key[j] = fetch(lane + 64 * j);
+        tiny_select(key, k, stage, lane, emit);
+        return;
+    }
+    for (int base = 0; base < n; base += 960) {
+#pragma unroll
+        for (int j = 0; j < 15; ++j) key[j] = fetch(base + lane + 64 * j);
+        key[15] = (base > 0 && lane < k) ? carry[lane] : 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // every lane holds its carried key before the row is rewritten
+        if (base + 960 >= n) tiny_select(key, k, stage, lane, emit);
+        else tiny_select(key, k, stage, lane, [&](int r, u64 kk) { carry[r] = kk; });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // geometry of the single-launch search: 0 = not applicable, 1 = flat (<= 32 panels), 2 = hierarchical
 struct TinyGeom { int kind, nwg, ppw; size_t off_cand, off_mm, bytes; };
-static TinyGeom tiny_geom(int nq, int npanels, int k, bool multi) {
+static TinyGeom tiny_geom(int nq, int npanels, int k, bool multi, int max_panels) {
     TinyGeom g{0, 1, 32, 0, 0, 0};
     if (nq > 16 || npanels <= 0 || k <= 0) return g;
     const size_t scores = ((size_t)nq * npanels * CMR_PANEL_ROWS * sizeof(float) + 255) & ~(size_t)255;
@@ -473,10 +498,12 @@ static TinyGeom tiny_geom(int nq, int npanels, int k, bool multi) {
         g.bytes = scores;
         return g;
     }
-    if (!multi || k > 64 || npanels > 2048) return g;
-    const int maxwg = std::min(64, 1024 / k);
+    if (!multi || k > 64 || npanels > max_panels) return g;
+    // workgroups: as many as there are 8-panel slices (up to 256) — but with >= 5 queries the final round is one wave per
+    // query over workgroups x k candidates, serial chunks of 960: keep it to one chunk while that costs <= 4 panels per wave
+    int maxwg = std::min(256, (npanels + 7) / 8);
+    if (nq > 4 && (npanels + 31) / 32 <= 1024 / k) maxwg = std::min(maxwg, 1024 / k);
     const int ppw = 8 * ((npanels + 8 * maxwg - 1) / (8 * maxwg));
-    if (ppw > 32) return g;
     g.kind = 2;
     g.ppw = ppw;
     g.nwg = (npanels + ppw - 1) / ppw;
@@ -495,6 +522,8 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     __shared__ int ticket;
     __shared__ u64 tiny_stage[8][64];       // per wave: the selection's surviving keys
+    __shared__ u64 tiny_carry[8][64];       // per wave: the running k best of a chunked selection
+    __shared__ u64 tiny_fin[8][64];         // the last workgroup's per-wave pre-selections of the final round
     uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64], then (stage_raw) the fp32 queries [nq][dim]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqt = (nq + 31) / 32;
@@ -553,25 +582,22 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const int row_lo = p_lo * CMR_PANEL_ROWS, nloc = (p_hi - p_lo) * CMR_PANEL_ROWS;      // <= 1024 rows
+        const int row_lo = p_lo * CMR_PANEL_ROWS, nloc = (p_hi - p_lo) * CMR_PANEL_ROWS;
         for (int qi = wave; qi < nq; qi += 8) {
-            u64 key[16];
             float mn = __builtin_inff(), mx = -__builtin_inff();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int lr = lane + 64 * j, row = row_lo + lr;
-                key[j] = 0ull;
-                if (lr < nloc && row < nrows) {
-                    const float v = scratch[(size_t)qi * ld + row];
-                    mn = fminf(mn, v); mx = fmaxf(mx, v);
-                    if (v == v) key[j] = cmr_make_key(v, (unsigned)row);
-                }
-            }
+            u64* dst = cand + ((size_t)blockIdx.x * nq + qi) * k;
+            tiny_select_stream(nloc, k, stage, tiny_carry[wave], lane,
+                               [&](int i) -> u64 {
+                                   const int row = row_lo + i;
+                                   if (i >= nloc || row >= nrows) return 0ull;
+                                   const float v = scratch[(size_t)qi * ld + row];
+                                   mn = fminf(mn, v); mx = fmaxf(mx, v);
+                                   return v == v ? cmr_make_key(v, (unsigned)row) : 0ull;
+                               },
+                               [&](int r, u64 kk) { dst[r] = kk; });
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
             if (lane == 0) part_mm[(size_t)blockIdx.x * nq + qi] = make_float2(mn, mx);
-            u64* dst = cand + ((size_t)blockIdx.x * nq + qi) * k;
-            tiny_select(key, k, stage, lane, [&](int r, u64 kk) { dst[r] = kk; });
         }
     }
     if (nwg > 1) {
@@ -587,55 +613,74 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    // Final selection among the workgroups' candidates.  With <= 4 queries the last workgroup's eight waves share it: P = 8,
+    // 4 or 2 waves per query pre-select over a P-th of the workgroups each (one chunk instead of up to six serial ones for
+    // one wave), then one wave per query selects among the P x k survivors.
+    const int fin_parts = (hier && nwg * k > 1024) ? (nq == 1 ? 8 : nq == 2 ? 4 : nq <= 4 ? 2 : 1) : 1;
+    if (fin_parts > 1) {
+        const int qi = wave / fin_parts, part = wave % fin_parts;
+        if (qi < nq) {
+            const int b0 = (int)((long long)part * nwg / fin_parts), b1 = (int)((long long)(part + 1) * nwg / fin_parts);
+            const int n1 = (b1 - b0) * k;
+            u64* dst = tiny_fin[wave];
+            tiny_select_stream(n1, k, stage, tiny_carry[wave], lane,
+                               [&](int i) -> u64 { return i < n1 ? cand[((size_t)(b0 + i / k) * nq + qi) * k + i % k] : 0ull; },
+                               [&](int r, u64 kk) { dst[r] = kk; });
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     for (int qi = wave; qi < nq; qi += 8) {
-        u64 key[16];
         float mn = __builtin_inff(), mx = -__builtin_inff();
+        auto emit = [&](int r, u64 kk) {
+            out_ids[(size_t)qi * k + r] = kk ? (int64_t)cmr_key_row(kk) + id_base : -1;
+            out_scores[(size_t)qi * k + r] = kk ? cmr_key_score(kk) : -__builtin_inff();
+        };
         if (!hier) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int row = lane + 64 * j;
-                key[j] = 0ull;
-                if (row < nrows) {
-                    const float v = scratch[(size_t)qi * ld + row];
-                    mn = fminf(mn, v); mx = fmaxf(mx, v);
-                    if (v == v) key[j] = cmr_make_key(v, (unsigned)row);
-                }
-            }
+            tiny_select_stream(nrows < 1024 ? nrows : 1024, k, stage, tiny_carry[wave], lane,
+                               [&](int row) -> u64 {
+                                   if (row >= nrows) return 0ull;
+                                   const float v = scratch[(size_t)qi * ld + row];
+                                   mn = fminf(mn, v); mx = fmaxf(mx, v);
+                                   return v == v ? cmr_make_key(v, (unsigned)row) : 0ull;
+                               },
+                               emit);
         } else {
-            const int ncand = nwg * k;                              // <= 1024
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int i = lane + 64 * j;
-                key[j] = i < ncand ? cand[((size_t)(i / k) * nq + qi) * k + i % k] : 0ull;
-            }
             for (int b = lane; b < nwg; b += 64) {
                 const float2 v = part_mm[(size_t)b * nq + qi];
                 mn = fminf(mn, v.x); mx = fmaxf(mx, v.y);
+            }
+            if (fin_parts > 1) {          // the waves' pre-selections (above), P x k keys in LDS
+                const int n2 = fin_parts * k;
+                tiny_select_stream(n2, k, stage, tiny_carry[wave], lane,
+                                   [&](int i) -> u64 { return i < n2 ? tiny_fin[qi * fin_parts + i / k][i % k] : 0ull; }, emit);
+            } else {
+                const int ncand = nwg * k;
+                tiny_select_stream(ncand, k, stage, tiny_carry[wave], lane,
+                                   [&](int i) -> u64 { return i < ncand ? cand[((size_t)(i / k) * nq + qi) * k + i % k] : 0ull; }, emit);
             }
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
         if (lane == 0) { if (out_min) out_min[qi] = mn; if (out_max) out_max[qi] = mx; }
-        tiny_select(key, k, stage, lane, [&](int r, u64 kk) {
-            out_ids[(size_t)qi * k + r] = kk ? (int64_t)cmr_key_row(kk) + id_base : -1;
-            out_scores[(size_t)qi * k + r] = kk ? cmr_key_score(kk) : -__builtin_inff();
-        });
     }
 }
 
-int cmr_tiny_kind(int nq, int npanels, int k, int multi) { return tiny_geom(nq, npanels, k, multi != 0).kind; }
-size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi) { return tiny_geom(nq, npanels, k, multi != 0).bytes; }
+int cmr_tiny_kind(int nq, int npanels, int k, int multi, int max_panels) { return tiny_geom(nq, npanels, k, multi != 0, max_panels).kind; }
+size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi, int max_panels) { return tiny_geom(nq, npanels, k, multi != 0, max_panels).bytes; }
 
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
                                   void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
-                                  hipStream_t s) {
+                                  int max_panels, hipStream_t s) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     const int nqt = (nq + 31) / 32;
     size_t lds = (size_t)nqt * ks * 1024;
-    const TinyGeom g = tiny_geom(nq, npanels, k, arrive != nullptr);
-    if (!g.kind || lds > 160 * 1024) return hipErrorInvalidValue;
-    const int stage_raw = lds + (size_t)nq * dim * 4 <= 160 * 1024 ? 1 : 0;      // fp32 at 1024-d: the operands alone take 128 KiB
+    const TinyGeom g = tiny_geom(nq, npanels, k, arrive != nullptr, max_panels);
+    constexpr size_t kDynLds = 160 * 1024 - 13 * 1024;                          // the kernel's static LDS (selection stage, carry and final rows) takes 12.3 KiB
+    if (!g.kind || lds > kDynLds) return hipErrorInvalidValue;
+    const int stage_raw = lds + (size_t)nq * dim * 4 <= kDynLds ? 1 : 0;          // fp32 at 1024-d: the operands alone take 128 KiB
     if (stage_raw) lds += (size_t)nq * dim * 4;
     const v4u* c = reinterpret_cast<const v4u*>(corpus);
     float* scores = reinterpret_cast<float*>(scratch);

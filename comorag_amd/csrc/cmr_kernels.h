@@ -67,14 +67,14 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
                                   float* out_min, float* out_max, u64* out_tau, hipStream_t s);
-// whole search of a small corpus in one launch (nq <= 16): kind 1 = <= 32 panels, kind 2 = hierarchical (up to 64 K rows while
-// workgroups x k <= 1024, k <= 64; needs the arrival counter), 0 = not applicable.  `arrive`: a zeroed device int the launches of
+// whole search of a small corpus in one launch (nq <= 16): kind 1 = <= 32 panels, kind 2 = hierarchical (up to max_panels panels,
+// k <= 64; needs the arrival counter), 0 = not applicable.  `arrive`: a zeroed device int the launches of
 // one stream share (nullptr: single-workgroup flat path only).
-int cmr_tiny_kind(int nq, int npanels, int k, int multi);
-size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi);
+int cmr_tiny_kind(int nq, int npanels, int k, int multi, int max_panels);
+size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi, int max_panels);
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
                                   void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
-                                  hipStream_t s);
+                                  int max_panels, hipStream_t s);
 // per-row top-k (k <= 4096) of a materialised score matrix [nq, ld]
 hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq, int k, long long id_base,
                                 int64_t* out_ids, float* out_scores, float* out_min, float* out_max, hipStream_t s);

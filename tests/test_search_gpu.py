@@ -77,12 +77,15 @@ def test_tiny_single_launch_path_equals_general_path(dtype, n, nq, k):
 @pytest.mark.parametrize("dtype,n,d,nq,k", [("bf16", 1025, 768, 1, 20), ("bf16", 3000, 768, 1, 20), ("bf16", 10_000, 768, 1, 20), ("f16", 10_000, 768, 16, 20),
                                             ("bf16", 13_057, 128, 5, 20), ("bf16", 13_058, 128, 5, 21), ("f32", 20_000, 100, 3, 5), ("bf16", 40_000, 256, 2, 20),
                                             ("bf16", 65_536, 64, 1, 16), ("bf16", 65_537, 64, 1, 16), ("bf16", 30_000, 64, 9, 64), ("bf16", 8_000, 64, 2, 65),
-                                            ("f32", 50_000, 1024, 1, 20), ("bf16", 2_000, 768, 1, 1)])
+                                            ("f32", 50_000, 1024, 1, 20), ("bf16", 2_000, 768, 1, 1), ("bf16", 100_000, 128, 1, 20),
+                                            ("bf16", 196_608, 64, 3, 20), ("bf16", 196_609, 64, 3, 20), ("f16", 190_000, 96, 16, 64), ("f32", 9_000, 1000, 8, 20),
+                                            ("bf16", 150_000, 64, 2, 33), ("bf16", 60_000, 64, 4, 64), ("bf16", 60_000, 64, 5, 64)])
 def test_small_corpus_single_launch_hierarchical_selection(dtype, n, d, nq, k):
-    """1025 rows .. 64 K rows, <= 16 queries, k <= 64: ONE launch — every workgroup scans its panels and selects the k best of
-    its rows, the last workgroup to arrive selects among the workgroups' candidates (tiny_search_kernel).  Must equal the
-    oracle and, bit for bit, the general pack / sample / scan / merge chain (CMR_SCAN_NO_SMALL=1); sizes just past the
-    limits (65 537 rows, k = 65, workgroups x k > 1024) take the general chain anyway."""
+    """1025 rows .. 192 K rows, <= 16 queries, k <= 64: ONE launch — every workgroup scans its panels and selects the k best of
+    its rows (in chunks of 960 with the running k best carried along when it has more than 1024), the last workgroup to
+    arrive selects among the workgroups' candidates the same way (tiny_search_kernel).  Must equal the oracle and, bit for
+    bit, the general pack / sample / scan / merge chain (CMR_SCAN_NO_SMALL=1); sizes just past the limits (196 609 rows,
+    k = 65) take the general chain anyway."""
     X, Q = _mk(n, d, nq, seed=n % 997 + nq + k)
     X[n - 1] = X[5]; X[n // 2] = X[5]; X[min(n - 1, 300)] = X[5]; Q[0] = X[5]      # one row four times: ties across workgroups and the last panel
     a_ids, a_sc = _check(dtype, X, Q, k)
