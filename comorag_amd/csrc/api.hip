@@ -1063,6 +1063,37 @@ int32_t cmr_index_scores(cmr_index_t* idx, const float* q, int32_t nq, float* ou
     if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
     struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
     hipStream_t s = ws->stream;
+    {   // Small corpus, few queries (dense_passage_retrieval / get_fact_scores on a few thousand rows, one query per call):
+        // ONE launch packs, scans and writes the scores straight into a pinned, device-mapped host buffer — no pack
+        // launch, no copies, one synchronisation (the general path: pageable H2D, pack, scan, 2-D D2H, flag D2H, two syncs).
+        const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
+        const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
+        const size_t sc_bytes = (size_t)nq * idx->n * 4, q_bytes = (size_t)nq * idx->dim * 4;
+        if (idx->zero_copy && !idx->no_tiny && !idx->no_small && nq <= 16 && npanels <= idx->small_max_panels && (size_t)ks * 1024 <= 147 * 1024 &&
+            sc_bytes <= 4 * kZeroCopyMax) {
+            const size_t o_sc = 256, o_q = (o_sc + sc_bytes + 255) & ~(size_t)255;
+            HIP_TRY(ws->ensure_pin(o_q + q_bytes));
+            char* h = (char*)ws->h_pin;
+            char* d = (char*)ws->h_pin_dev;
+            memcpy(h + o_q, q, q_bytes);
+            memset(h, 0, 8);
+            const float* q_in = (const float*)(d + o_q);
+            if (npanels > 32) {               // many workgroups pack the queries: from a device copy, not across the link once each
+                HIP_TRY(ws->d_q.ensure(q_bytes));
+                HIP_TRY(hipMemcpyAsync(ws->d_q.p, h + o_q, q_bytes, hipMemcpyHostToDevice, s));
+                q_in = (const float*)ws->d_q.p;
+            }
+            HIP_TRY(ws->d_out.ensure((size_t)nq * npanels * CMR_PANEL_ROWS * 4));
+            HIP_TRY(cmr_launch_tiny_scores(idx->dtype, idx->corpus, q_in, nq, idx->dim, idx->dpad, idx->n, ws->d_out.p, (float*)(d + o_sc), idx->n,
+                                           (int*)d, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            int flagged = 0;
+            memcpy(&flagged, h, sizeof(int));
+            if (flagged) return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+            for (int qi = 0; qi < nq; ++qi) memcpy(out + (size_t)qi * ld, h + o_sc + (size_t)qi * idx->n * 4, (size_t)idx->n * 4);
+            return CMR_OK;
+        }
+    }
     HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
     HIP_TRY(ws->d_out.ensure((size_t)nq * idx->n * 4));
     HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));

@@ -402,6 +402,8 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 //     also selects the k best of ITS rows per query and publishes them with its min / max; the last one to arrive
 //     selects among the workgroups' candidates.  The k best rows overall are among the k best of their workgroup, so the
 //     result is exact.
+//   * scores mode (out_full != nullptr: all N raw scores of every query, what dense_passage_retrieval / get_fact_scores
+//     consume): scan, then every workgroup copies its rows to the caller's buffer with coalesced stores — no selection.
 // Selection by one wave over <= 16 keys per lane (0 = empty, keys unique), without rounds for k <= 64: k rounds of
 // "wave-wide arg-max, remove" cost ~1300 cycles each — 13 us at k = 20.  Instead the k-th largest of the 64 per-lane maxima
 // T is a lower bound of the k-th best key (k lanes hold a key >= T), so only keys >= T can win; those survivors (k .. a
@@ -518,7 +520,8 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
                                                           int nrows, int npanels, int k, long long id_base, float* __restrict__ scratch,
                                                           int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                                           float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag, int stage_raw,
-                                                          int* __restrict__ arrive, int ppw, u64* __restrict__ cand, float2* __restrict__ part_mm) {
+                                                          int* __restrict__ arrive, int ppw, u64* __restrict__ cand, float2* __restrict__ part_mm,
+                                                          float* __restrict__ out_full, long long ld_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     __shared__ int ticket;
     __shared__ u64 tiny_stage[8][64];       // per wave: the selection's surviving keys
@@ -576,6 +579,15 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
                 for (int r = 0; r < 16; ++r) scratch[(size_t)qi * ld + p * CMR_PANEL_ROWS + cmr_acc_row(r, lane)] = acc[r];
             }
         }
+    }
+    if (out_full) {     // SCORES MODE (cmr_index_scores): this workgroup's rows of every query, coalesced, straight to the caller's buffer
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int row_lo = p_lo * CMR_PANEL_ROWS, row_hi = p_hi * CMR_PANEL_ROWS < nrows ? p_hi * CMR_PANEL_ROWS : nrows;
+        for (int qi = 0; qi < nq; ++qi)
+            for (int row = row_lo + tid; row < row_hi; row += 512) out_full[(size_t)qi * ld_out + row] = scratch[(size_t)qi * ld + row];
+        return;
     }
     u64* stage = tiny_stage[wave];
     if (hier) {         // the k best of this workgroup's rows, per query
@@ -670,14 +682,21 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
 int cmr_tiny_kind(int nq, int npanels, int k, int multi, int max_panels) { return tiny_geom(nq, npanels, k, multi != 0, max_panels).kind; }
 size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi, int max_panels) { return tiny_geom(nq, npanels, k, multi != 0, max_panels).bytes; }
 
-hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
-                                  void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
-                                  int max_panels, hipStream_t s) {
+static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
+                              void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
+                              int max_panels, float* out_full, long long ld_out, hipStream_t s) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     const int nqt = (nq + 31) / 32;
     size_t lds = (size_t)nqt * ks * 1024;
-    const TinyGeom g = tiny_geom(nq, npanels, k, arrive != nullptr, max_panels);
+    TinyGeom g = tiny_geom(nq, npanels, k, arrive != nullptr, max_panels);
+    if (out_full) {     // scores mode: no selection, as many workgroups as there are 8-panel slices (up to 256)
+        if (nq > 16 || npanels <= 0) return hipErrorInvalidValue;
+        const int maxwg = std::min(256, (npanels + 7) / 8);
+        g.kind = 1;
+        g.ppw = 8 * ((npanels + 8 * maxwg - 1) / (8 * maxwg));
+        g.nwg = (npanels + g.ppw - 1) / g.ppw;
+    }
     constexpr size_t kDynLds = 160 * 1024 - 13 * 1024;                          // the kernel's static LDS (selection stage, carry and final rows) takes 12.3 KiB
     if (!g.kind || lds > kDynLds) return hipErrorInvalidValue;
     const int stage_raw = lds + (size_t)nq * dim * 4 <= kDynLds ? 1 : 0;          // fp32 at 1024-d: the operands alone take 128 KiB
@@ -691,7 +710,7 @@ hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q,
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                                               \
         hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(g.nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scores, out_ids, \
-                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm);                                 \
+                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm, out_full, ld_out);              \
     }
     switch (dtype) {
         case CMR_DT_BF16: TS(CMR_DT_BF16) break;
@@ -701,6 +720,19 @@ hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q,
     }
 #undef TS
     return hipGetLastError();
+}
+
+hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
+                                  void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
+                                  int max_panels, hipStream_t s) {
+    return tiny_launch(dtype, corpus, q, nq, dim, dpad, nrows, k, id_base, scratch, out_ids, out_scores, out_min, out_max, flag, arrive, max_panels,
+                       nullptr, 0, s);
+}
+
+// all raw scores [nq, ld_out] of a small corpus (nq <= 16) in one launch; scratch: nq * npanels * 32 floats
+hipError_t cmr_launch_tiny_scores(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, void* scratch,
+                                  float* out, long long ld_out, int* flag, hipStream_t s) {
+    return tiny_launch(dtype, corpus, q, nq, dim, dpad, nrows, 1, 0, scratch, nullptr, nullptr, nullptr, nullptr, flag, nullptr, 1 << 30, out, ld_out, s);
 }
 
 // ------------------------------------------------------------------------------------------

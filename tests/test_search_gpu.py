@@ -94,6 +94,37 @@ def test_small_corpus_single_launch_hierarchical_selection(dtype, n, d, nq, k):
     assert sorted(a_ids[0][:4].tolist()) == sorted({5, min(n - 1, 300), n // 2, n - 1}) or k < 4
 
 
+@pytest.mark.parametrize("dtype,n,d,nq", [("bf16", 1, 768, 1), ("bf16", 6, 768, 1), ("bf16", 1000, 768, 3), ("f32", 1025, 200, 1), ("f16", 10_000, 768, 16),
+                                          ("bf16", 33_333, 128, 2), ("bf16", 196_608, 64, 1), ("f32", 100_001, 64, 2), ("bf16", 50_000, 64, 16)])
+def test_scores_single_launch_equals_general_path(dtype, n, d, nq):
+    """cmr_index_scores on a small corpus (what dense_passage_retrieval / get_fact_scores call, one query at a time): one launch
+    that packs, scans and writes the scores into a mapped host buffer.  Must equal, bit for bit, the general pack + scan
+    (operands swapped: D[query][row]) + copy path (CMR_SCAN_NO_SMALL=1), and the oracle; a NaN query is still reported."""
+    from comorag_amd import _lib
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(n, d, nq, seed=n % 991 + nq)
+    outs = []
+    for env in ({}, {"CMR_SCAN_NO_SMALL": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            idx = DenseIndex(d, dtype)
+            idx.append(X)
+            outs.append(idx.scores(Q))
+            if not env:
+                bad = Q.copy(); bad[0, 1] = np.inf
+                with pytest.raises(_lib.CmrError):
+                    idx.scores(bad)
+                assert np.array_equal(idx.scores(Q), outs[0])
+            idx.close()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert outs[0].shape == (nq, n) and np.array_equal(outs[0], outs[1])
+    rnd = ROUND[dtype]
+    np.testing.assert_allclose(outs[0], orc.exact_scores_f64(rnd(X), rnd(Q)), atol=ERR, rtol=0)
+
+
 @pytest.mark.parametrize("n,nq,k", [(6, 1, 5), (1000, 3, 20), (5000, 1, 20), (140_000, 1, 20), (140_000, 8, 20), (20_000, 64, 20), (3000, 2, 100)])
 def test_zero_copy_host_api_equals_copy_path(n, nq, k):
     """The synchronous host API maps queries / results / the non-finite flag from pinned host memory (no copies around the

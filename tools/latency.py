@@ -18,6 +18,9 @@ for rows in [int(x) for x in (sys.argv[1:] or ["6", "1000", "100000", "1000000",
         t = []
         for _ in range(50):
             t0 = time.perf_counter(); idx.search(q, min(k, rows)); t.append(time.perf_counter() - t0)
-        t0 = time.perf_counter(); s = idx.scores(q[:1]); ts = time.perf_counter() - t0
-        print(f"rows {rows:>9} B {B:>3} k {min(k, rows):>3}: search median {np.median(t)*1e6:8.1f} us  min {np.min(t)*1e6:8.1f} us   | full scores(B=1) {ts*1e6:8.1f} us", flush=True)
+        for _ in range(3): idx.scores(q[:1])
+        ts = []
+        for _ in range(30):
+            t0 = time.perf_counter(); s = idx.scores(q[:1]); ts.append(time.perf_counter() - t0)
+        print(f"rows {rows:>9} B {B:>3} k {min(k, rows):>3}: search median {np.median(t)*1e6:8.1f} us  min {np.min(t)*1e6:8.1f} us   | full scores(B=1) median {np.median(ts)*1e6:8.1f} us", flush=True)
     idx.close()
