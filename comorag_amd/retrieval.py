@@ -13,7 +13,10 @@ import numpy as np
 from .index import DenseIndex
 from .utils.misc_utils import min_max_normalize
 
-DEVICE_SORT_MIN_ROWS = 4096     # below this the host argsort of N floats is cheaper than 26 tiny launches
+# Complete ranking of one query: below this, numpy's argsort of the N GPU scores (single-launch cmr_index_scores + ~9 ns per
+# row) beats the device radix sort's 26 launches + 12 N bytes of D2H (measured, profiles/r2_full_ranking_crossover.txt:
+# 32 / 85 / 181 us against 189 / 242 / 251 us at 1 K / 8 K / 20 K rows; 363 against 270 us at 40 K)
+DEVICE_SORT_MIN_ROWS = 28_672
 QUERY_INSTRUCTION_SUMMARIES = "Given a question, retrieve relevant documents that best answer the question."
 
 
@@ -38,7 +41,7 @@ def dense_passage_retrieval(index: DenseIndex, query_embedding) -> Tuple[np.ndar
         query_doc_scores = full_scores(index, query_embedding)
         query_doc_scores = min_max_normalize(query_doc_scores)
         sorted_doc_ids = np.argsort(query_doc_scores)[::-1]
-        sorted_doc_scores = query_doc_scores[sorted_doc_ids.tolist()]
+        sorted_doc_scores = query_doc_scores[sorted_doc_ids]      # (the reference indexes with .tolist(): same values, N Python ints)
         return sorted_doc_ids, sorted_doc_scores
     ids, raw, mn, mx = index.sorted_scores(_as_query(query_embedding)[:1])     # scan + stable radix sort on the GPU
     rng = mx[0] - mn[0]

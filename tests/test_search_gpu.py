@@ -338,7 +338,7 @@ def test_dense_passage_retrieval_device_sort_matches_reference_lines():
     reference's normalise + argsort lines give on the same scores (ComoRAG.py:950-967), ties aside."""
     from comorag_amd import retrieval
     from comorag_amd.index import DenseIndex
-    n, d = 20011, 96
+    n, d = 40009, 96
     assert n >= retrieval.DEVICE_SORT_MIN_ROWS
     X, Q = _mk(n, d, 1, seed=22)
     idx = DenseIndex(d, "f32"); idx.append(X)
