@@ -225,7 +225,7 @@ def single_query_latency(torch, args, device, sizes=(6, 1000, 10_000, 100_000)):
     """What ComoRAG's per-question threads issue (ComoRAG.py:937-967 is one query per call): median wall time of a
     synchronous single-query top-k through the host-buffer API, Python wrapper included, per corpus size."""
     from comorag_amd.index import DenseIndex
-    out = {}
+    out, all_scores = {}, {}
     rng = np.random.default_rng(11)
     for rows in sizes:
         idx = DenseIndex(args.dim, args.dtype, device=device.index or 0, capacity_hint=rows)
@@ -243,8 +243,17 @@ def single_query_latency(torch, args, device, sizes=(6, 1000, 10_000, 100_000)):
             idx.search(q1, kk)
             t.append(time.perf_counter() - t0)
         out[str(rows)] = float(np.median(t) * 1e6)
+        for _ in range(5):
+            idx.scores(q1)
+        t = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            idx.scores(q1)
+            t.append(time.perf_counter() - t0)
+        all_scores[str(rows)] = float(np.median(t) * 1e6)
         idx.close()
-    return {"unit": "us per call (median of 50)", "rows": out}
+    return {"unit": "us per call (median of 50)", "rows": out,
+            "all_scores_rows": all_scores, "all_scores_note": "cmr_index_scores, one query: what dense_passage_retrieval / get_fact_scores call (median of 30)"}
 
 
 def encode_rate(torch, device, kind="base", n_chunks=256, dtype="auto"):
