@@ -111,6 +111,7 @@ struct Workspace {
 
 struct ProfEvent { hipEvent_t a, b; };
 
+constexpr size_t kMappedAppendMax = 64 * 1024;  // appends up to this many bytes of fp32 rows are read by the convert kernel from mapped host memory
 constexpr size_t kZeroCopyMax = 256 * 1024;   // synchronous host API: queries / results up to this size are mapped, not copied
 
 struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullptr, main_done = nullptr; bool used = false; };
@@ -133,6 +134,9 @@ struct cmr_index {
     std::vector<Workspace*> free_ws;            // for the synchronous host API
     std::map<hipStream_t, Workspace*> stream_ws;  // for the _dev API
     DevBuf stage;                // append staging
+    void* h_pin = nullptr;       // small appends: pinned, device-mapped rows + flag (exclusive lock held)
+    void* h_pin_dev = nullptr;
+    size_t h_pin_cap = 0;
     int* d_flag = nullptr;       // non-finite flag for appends
     // profiling
     std::mutex prof_mu;
@@ -788,6 +792,7 @@ int32_t cmr_index_destroy(cmr_index_t* idx) {
         if (idx->pipe.sm) (void)hipStreamDestroy(idx->pipe.sm);
         if (idx->pipe.sq) (void)hipStreamDestroy(idx->pipe.sq);
         idx->stage.release();
+        if (idx->h_pin) { (void)hipHostFree(idx->h_pin); idx->h_pin = nullptr; idx->h_pin_cap = 0; }
         if (idx->corpus) (void)hipFree(idx->corpus);
         if (idx->shadow) (void)hipFree(idx->shadow);
         if (idx->d_flag) (void)hipFree(idx->d_flag);
@@ -825,6 +830,29 @@ int32_t cmr_index_append(cmr_index_t* idx, const float* rows, int64_t n) {
     if (idx->n + n >= 0xFFFFFFF0ll) return fail(CMR_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
     rc = grow(idx, (idx->n + n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     if (rc) return rc;
+    if (idx->zero_copy && (size_t)n * idx->dim * 4 <= kMappedAppendMax) {
+        // A handful of rows (MemoryPool's per-cycle nodes, a store's freshly inserted strings): rows and the non-finite flag
+        // in a pinned, device-mapped buffer that the convert kernel reads / writes itself — one launch and one
+        // synchronisation instead of a pageable H2D, a memset, the launch, the flag's D2H and the synchronisation.
+        const size_t bytes = (size_t)n * idx->dim * 4;
+        if (bytes + 256 > idx->h_pin_cap) {
+            if (idx->h_pin) { HIP_TRY(hipHostFree(idx->h_pin)); idx->h_pin = nullptr; idx->h_pin_cap = 0; }
+            HIP_TRY(hipHostMalloc(&idx->h_pin, kMappedAppendMax + 256, hipHostMallocDefault));
+            HIP_TRY(hipHostGetDevicePointer(&idx->h_pin_dev, idx->h_pin, 0));
+            idx->h_pin_cap = kMappedAppendMax + 256;
+        }
+        char* h = (char*)idx->h_pin;
+        char* d = (char*)idx->h_pin_dev;
+        memset(h, 0, 8);
+        memcpy(h + 256, rows, bytes);
+        HIP_TRY(cmr_launch_convert_rows(idx->dtype, (const float*)(d + 256), n, idx->dim, idx->dpad, idx->n, idx->corpus, idx->shadow, (int*)d, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        int flagged = 0;
+        memcpy(&flagged, h, sizeof(int));
+        if (flagged) return fail(CMR_ERR_NONFINITE, "appended rows contain NaN/Inf (index unchanged)");
+        idx->n += n;
+        return CMR_OK;
+    }
     // stage in chunks of <= 256 MiB of fp32
     const long long chunk_rows = std::max<long long>(1, (256ll << 20) / ((long long)idx->dim * 4));
     const long long n0 = idx->n;
