@@ -1178,6 +1178,29 @@ int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const in
     if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
     struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
     hipStream_t s = ws->stream;
+    {   // few queries (the exact re-scorer behind a top-100 search): candidates + queries go down in ONE copy from the pinned
+        // buffer (the kernel re-reads each query once per candidate: not across the link), the results are written straight
+        // into its mapped half — one copy, one launch, one sync instead of two copies each way
+        const size_t q_bytes = (size_t)nq * idx->dim * 4, c_bytes = ((size_t)nq * n_cand * 8 + 255) & ~(size_t)255, i_bytes = (size_t)nq * k * 8,
+                     s_bytes = (size_t)nq * k * 4;
+        if (idx->zero_copy && i_bytes + s_bytes <= kZeroCopyMax && c_bytes + q_bytes <= 16 * kZeroCopyMax) {
+            const size_t o_ids = 0, o_sc = o_ids + i_bytes, o_in = (o_sc + s_bytes + 255) & ~(size_t)255;
+            HIP_TRY(ws->ensure_pin(o_in + c_bytes + q_bytes));
+            HIP_TRY(ws->d_cand.ensure(c_bytes + q_bytes));
+            char* h = (char*)ws->h_pin;
+            char* d = (char*)ws->h_pin_dev;
+            memcpy(h + o_in, cand, (size_t)nq * n_cand * 8);
+            memcpy(h + o_in + c_bytes, q, q_bytes);
+            HIP_TRY(hipMemcpyAsync(ws->d_cand.p, h + o_in, c_bytes + q_bytes, hipMemcpyHostToDevice, s));
+            HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, idx->id_base,
+                                       (const float*)((const char*)ws->d_cand.p + c_bytes), nq, (const int64_t*)ws->d_cand.p, n_cand, k,
+                                       (int64_t*)(d + o_ids), (float*)(d + o_sc), s));
+            HIP_TRY(hipStreamSynchronize(s));
+            memcpy(out_ids, h + o_ids, i_bytes);
+            memcpy(out_scores, h + o_sc, s_bytes);
+            return CMR_OK;
+        }
+    }
     HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
     HIP_TRY(ws->d_cand.ensure((size_t)nq * n_cand * 8));
     HIP_TRY(ws->d_ids.ensure((size_t)nq * k * 8));
