@@ -349,7 +349,7 @@ hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int n
     if (W > 16 * MERGE_THREADS) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * k * 8 + (size_t)(W + 1) * 4 + MERGE_WAVES * 4 + 256 * 4 + 4 * 4 + 2 * MERGE_WAVES * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_query_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);     // a constant: per function, not per launch
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_query_kernel, dim3(nq), dim3(MERGE_THREADS), lds, s, lists, cnt, W, nq_stride, cap, k, mm, id_base,
                        out_ids, out_scores, out_min, out_max, out_tau);
@@ -707,7 +707,8 @@ static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int
     float2* pmm = g.kind == 2 ? reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + g.off_mm) : nullptr;
 #define TS(DT)                                                                                                                       \
     {                                                                                                                                \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        /* a constant: the attribute is per function, not per launch, and host threads launch concurrently with different sizes */              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLds); \
         if (e != hipSuccess) return e;                                                                                               \
         hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(g.nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scores, out_ids, \
                            out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm, out_full, ld_out);              \
@@ -868,7 +869,7 @@ hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq
     while (kpad < (k < n ? k : n)) kpad <<= 1;
     const size_t lds = (size_t)kpad * 8 + 256 * 4 + 8 * 4 + 4 * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_rows_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);     // a constant: per function, not per launch
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(topk_rows_kernel, dim3(nq), dim3(256), lds, s, scores, ld, n, k, kpad, id_base, out_ids, out_scores,
                        out_min, out_max);
@@ -1105,7 +1106,7 @@ hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow
 #define RS(DT)                                                                                                        \
     {                                                                                                                 \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rescore_kernel<DT>),                         \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);                    \
         if (e != hipSuccess) return e;                                                                                \
         hipLaunchKernelGGL(rescore_kernel<DT>, grid, block, lds, s, c, shadow, dim, ks, nrows, id_base, q, cand, n_cand, k, \
                            out_ids, out_scores);                                                                      \

@@ -99,7 +99,7 @@ static hipError_t launch_pack(const int64_t* ids, const float* scores, long long
 }
 static hipError_t launch_merge_keys(const u64* keys, int S, int nq, int k, int64_t* out_ids, float* out_scores, hipStream_t s) {
     const size_t lds = (size_t)S * k * 8;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_keys_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);   // a constant: per function, not per launch
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(merge_keys_kernel, dim3(nq), dim3(256), lds, s, keys, S, nq, k, out_ids, out_scores);
     return hipGetLastError();

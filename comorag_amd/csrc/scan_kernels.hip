@@ -361,8 +361,10 @@ template <int DT, int NQT, int CAP, int R, int MODE>
 static hipError_t launch_one(const CmrScanGeom& g, const ScanP& p, hipStream_t s) {
     // occupancy follows from LDS: <= 80 KiB of query fragments -> two workgroups per CU
     auto launch = [&](auto kern) -> hipError_t {
+        // (the limit, not this launch's size: the attribute is per function and host threads launch concurrently —
+        // two indexes of different width would otherwise race each other's value)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(g.grid), dim3(CMR_SCAN_THREADS), g.lds, s, p);
         return hipGetLastError();
@@ -988,7 +990,7 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipS
     const ScanP p = to_p(g, a);
     const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap);
     auto launch = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, dim3(g.grid), dim3(WIDE_WAVES * 64), lds, s, p);
         return hipGetLastError();
