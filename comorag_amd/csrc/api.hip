@@ -151,7 +151,7 @@ struct cmr_index {
     int force_grid = 0;      // CMR_SCAN_GRID
     int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
     int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
-    int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch path for corpora of <= 1024 rows
+    int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch paths (search and all-scores) altogether
     int single_level = 1;    // CMR_SAMPLE_SINGLE=0: small batches on mid-size corpora sample in two levels like everything else
     int tiny_multi = 1;      // CMR_TINY_MULTI=0: the single-launch path always runs as one workgroup (<= 1024 rows only)
     int small_max_panels = 6144;   // CMR_SMALL_MAX_PANELS: largest corpus (in 32-row panels) the single-launch path takes

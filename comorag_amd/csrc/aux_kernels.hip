@@ -398,10 +398,11 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 //   * <= 32 panels (1024 rows): up to four workgroups scan 8 panels each (a wave streams its panels one after the
 //     other, 3.6 us each), the LAST one to arrive — release fence, ticket from a self-re-arming counter, acquire fence —
 //     selects among all rows (one wave per query, <= 16 keys per lane).
-//   * more panels (HIER, up to 64 workgroups x 32 panels = 64 K rows as long as workgroups x k <= 1024): every workgroup
-//     also selects the k best of ITS rows per query and publishes them with its min / max; the last one to arrive
-//     selects among the workgroups' candidates.  The k best rows overall are among the k best of their workgroup, so the
-//     result is exact.
+//   * more panels (HIER, up to 256 workgroups, up to the caller's panel limit — 6144 panels = 192 K rows by default —, k <= 64):
+//     every workgroup also selects the k best of ITS rows per query (more than 1024 rows: in chunks of 960 with the running
+//     k best carried along) and publishes them with its min / max; the last one to arrive selects among the workgroups'
+//     candidates, its eight waves sharing that round when there are <= 4 queries.  The k best rows overall are among the k
+//     best of their workgroup, so the result is exact.
 //   * scores mode (out_full != nullptr: all N raw scores of every query, what dense_passage_retrieval / get_fact_scores
 //     consume): scan, then every workgroup copies its rows to the caller's buffer with coalesced stores — no selection.
 // Selection by one wave over <= 16 keys per lane (0 = empty, keys unique), without rounds for k <= 64: k rounds of
