@@ -50,6 +50,7 @@ SIGNATURES = {
     "cmr_index_search_dev": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cmr_index_search_pipelined": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _P(_p)]),
     "cmr_index_set_id_base": (_i32, [_p, _i64]),
+    "cmr_index_set_id_blocks": (_i32, [_p, _i32, _p, _p]),
     "cmr_index_pipeline_stream": (_i32, [_p, _i32, _P(_p)]),
     "cmr_index_query_status": (_i32, [_p, _P(_i32)]),
     "cmr_stream_wait_event": (_i32, [_p, _p]),
@@ -71,6 +72,7 @@ SIGNATURES = {
     "cmr_comm_unique_id": (_i32, [_p]),
     "cmr_comm_create": (_i32, [_i32, _i32, _p, _i32, _P(_p)]),
     "cmr_comm_destroy": (_i32, [_p]),
+    "cmr_comm_info": (_i32, [_p, _P(_i32), _P(_i32), _P(_i32)]),
     "cmr_comm_allgather_merge": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p]),
     "cmr_pool_l2norm": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_profile_enable": (_i32, [_p, _i32]),

@@ -158,6 +158,12 @@ struct cmr_index {
     int no_small = 0;        // CMR_SCAN_NO_SMALL=1: corpora of 1025 rows .. 64 K rows take the general path also for few queries
     int zero_copy = 1;       // CMR_ZERO_COPY=0: the synchronous host API copies queries / results instead of mapping them
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
+    // A row shard that took incremental appends holds several runs of consecutive global ids (cmr_index_set_id_blocks): the
+    // kernels then run with base 0 and a remap launch translates their ids; candidate / row ids coming IN are translated
+    // on the host.  One block = plain id_base.
+    std::vector<long long> blk_local, blk_global;
+    long long* d_blk = nullptr;          // [local0[nb] | global0[nb]] on the device
+    std::vector<void*> blk_retired;      // earlier tables: in-flight searches may still read them (a few bytes each, freed at destroy)
     int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
     int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
     int pipe_slots = 3;      // CMR_PIPE_SLOTS (2..4): batches in the pipeline.  A third slot lets the pre-phase of batch i+2 start before
@@ -173,6 +179,30 @@ namespace {
 int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+}
+
+// id base the kernels add themselves (0 when a block table translates afterwards)
+long long kernel_id_base(const cmr_index* idx) { return idx->blk_local.size() > 1 ? 0 : idx->id_base; }
+// shard-local ids -> global ids, on the stream that produced them (no-op for a single block)
+int remap_ids_enqueue(cmr_index* idx, int64_t* ids_dev, long long n, hipStream_t s);
+// global id -> shard-local row, -1 when this shard does not hold it
+long long to_local_row(const cmr_index* idx, long long gid) {
+    if (gid < 0) return -1;
+    if (idx->blk_local.size() <= 1) { const long long r = gid - idx->id_base; return (r >= 0 && r < idx->n) ? r : -1; }
+    const size_t nb = idx->blk_local.size();
+    size_t b = std::upper_bound(idx->blk_global.begin(), idx->blk_global.end(), gid) - idx->blk_global.begin();
+    if (b == 0) return -1;
+    --b;
+    const long long len = (b + 1 < nb ? idx->blk_local[b + 1] : idx->n) - idx->blk_local[b];
+    const long long off = gid - idx->blk_global[b];
+    return off < len ? idx->blk_local[b] + off : -1;
+}
+
+// would appending n rows push the last block's global ids past what the packed exchange can carry?
+bool global_id_overflow(const cmr_index* idx, long long n) {
+    const long long l0 = idx->blk_local.size() > 1 ? idx->blk_local.back() : 0;
+    const long long g0 = idx->blk_local.size() > 1 ? idx->blk_global.back() : idx->id_base;
+    return g0 + (idx->n + n - l0) - 1 > 0xFFFFFFFEll;
 }
 
 int set_device(int device) {
@@ -210,6 +240,12 @@ int arm_flag(Workspace* ws, hipStream_t s) {
     HIP_TRY(ws->flag.ensure(sizeof(int)));
     HIP_TRY(hipMemsetAsync(ws->flag.p, 0, sizeof(int), s));
     ws->flag_ptr = (int*)ws->flag.p;
+    return CMR_OK;
+}
+
+int remap_ids_enqueue(cmr_index* idx, int64_t* ids_dev, long long n, hipStream_t s) {
+    if (idx->blk_local.size() <= 1) return CMR_OK;
+    HIP_TRY(cmr_launch_remap_ids(ids_dev, n, idx->d_blk, (int)idx->blk_local.size(), s));
     return CMR_OK;
 }
 
@@ -289,11 +325,11 @@ int search_large_k_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, in
         const int nb = std::min(blockq, nq - q0);
         int rc = scores_enqueue(idx, ws, q_dev + (size_t)q0 * idx->dim, nb, (float*)ws->d_out.p, ld);
         if (rc) return rc;
-        HIP_TRY(cmr_launch_topk_rows((const float*)ws->d_out.p, ld, (int)n, nb, k, idx->id_base, ids_dev + (size_t)q0 * k,
+        HIP_TRY(cmr_launch_topk_rows((const float*)ws->d_out.p, ld, (int)n, nb, k, kernel_id_base(idx), ids_dev + (size_t)q0 * k,
                                      scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                                      max_dev ? max_dev + q0 : nullptr, s));
     }
-    return CMR_OK;
+    return remap_ids_enqueue(idx, ids_dev, (long long)nq * k, s);
 }
 
 // Every wave (workgroup, for the wide kernel) scans a contiguous range of floor/ceil(npanels / W) panels and
@@ -476,8 +512,8 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(hipStreamWaitEvent(sq, ev_scan, 0));
     }
     HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, (const float2*)ws->mm.p,
-                                   idx->id_base, ids_dev, scores_dev, min_dev, max_dev, nullptr, sq));
-    return CMR_OK;
+                                   kernel_id_base(idx), ids_dev, scores_dev, min_dev, max_dev, nullptr, sq));
+    return remap_ids_enqueue(idx, ids_dev, (long long)nqp * k, sq);
 }
 
 // 0: the general pack / [sample] / scan / merge chain; 1: single launch, <= 1024 rows; 2: single launch, hierarchical
@@ -507,9 +543,9 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
             HIP_TRY(ws->arrive.ensure(sizeof(int)));
             HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), ws->stream));
         }
-        HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, idx->id_base, ws->d_out.p,
+        HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, kernel_id_base(idx), ws->d_out.p,
                                        ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, idx->small_max_panels, ws->stream));
-        return CMR_OK;
+        return remap_ids_enqueue(idx, ids_dev, (long long)nq * k, ws->stream);
     }
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
@@ -796,6 +832,8 @@ int32_t cmr_index_destroy(cmr_index_t* idx) {
         if (idx->corpus) (void)hipFree(idx->corpus);
         if (idx->shadow) (void)hipFree(idx->shadow);
         if (idx->d_flag) (void)hipFree(idx->d_flag);
+        if (idx->d_blk) (void)hipFree(idx->d_blk);
+        for (void* p : idx->blk_retired) (void)hipFree(p);
     }
     delete idx;
     return CMR_OK;
@@ -828,6 +866,7 @@ int32_t cmr_index_append(cmr_index_t* idx, const float* rows, int64_t n) {
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (idx->n + n >= 0xFFFFFFF0ll) return fail(CMR_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    if (global_id_overflow(idx, n)) return fail(CMR_ERR_UNSUPPORTED, "appending %lld rows takes this shard's global ids beyond the 32-bit row of the packed candidate exchange", (long long)n);
     rc = grow(idx, (idx->n + n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     if (rc) return rc;
     if (idx->zero_copy && (size_t)n * idx->dim * 4 <= kMappedAppendMax) {
@@ -876,6 +915,7 @@ int32_t cmr_index_append_dev(cmr_index_t* idx, const float* rows_dev, int64_t n,
     int rc = set_device(idx->device);
     if (rc) return rc;
     if (idx->n + n >= 0xFFFFFFF0ll) return fail(CMR_ERR_UNSUPPORTED, "more than 2^32 rows per shard");
+    if (global_id_overflow(idx, n)) return fail(CMR_ERR_UNSUPPORTED, "appending %lld rows takes this shard's global ids beyond the 32-bit row of the packed candidate exchange", (long long)n);
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipStreamSynchronize(s));  // rows_dev producer done before a possible grow() reallocates
     rc = grow(idx, (idx->n + n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
@@ -910,10 +950,48 @@ int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_dev, int32_t
     return rc;
 }
 
+// the packed candidate exchange (comm.hip) carries the global row in 32 bits: 0xFFFFFFFF - row, key 0 = empty
+static const long long kMaxGlobalId = 0xFFFFFFFEll;
+
 int32_t cmr_index_set_id_base(cmr_index_t* idx, int64_t base) {
     if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
+    if (base < 0) return fail(CMR_ERR_INVALID, "id base %lld < 0", (long long)base);
     std::unique_lock<std::shared_mutex> lk(idx->mu);
+    if (base + idx->n - 1 > kMaxGlobalId)
+        return fail(CMR_ERR_UNSUPPORTED, "id base %lld + %lld rows exceeds the 32-bit global row of the packed candidate exchange", (long long)base, idx->n);
     idx->id_base = base;
+    idx->blk_local.clear(); idx->blk_global.clear();
+    return CMR_OK;
+}
+
+int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_t* local_start, const int64_t* global_start) {
+    if (!idx || n_blocks <= 0 || !local_start || !global_start) return fail(CMR_ERR_INVALID, "bad argument");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    if (local_start[0] != 0) return fail(CMR_ERR_INVALID, "the first block must start at local row 0");
+    for (int b = 0; b < n_blocks; ++b) {
+        const long long len = (b + 1 < n_blocks ? local_start[b + 1] : std::max<long long>(idx->n, local_start[b])) - local_start[b];
+        if (global_start[b] < 0 || len < 0 || (b > 0 && (local_start[b] <= local_start[b - 1] || global_start[b] < global_start[b - 1] + (local_start[b] - local_start[b - 1]))))
+            return fail(CMR_ERR_INVALID, "block %d: local starts must ascend and the global id runs must ascend without overlap", b);
+        if (global_start[b] + len - 1 > kMaxGlobalId)
+            return fail(CMR_ERR_UNSUPPORTED, "block %d reaches global id %lld: the packed candidate exchange carries 32-bit rows", b, (long long)(global_start[b] + len - 1));
+    }
+    if (n_blocks == 1) {
+        idx->id_base = global_start[0];
+        idx->blk_local.clear(); idx->blk_global.clear();
+        return CMR_OK;
+    }
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    std::vector<long long> tab((size_t)2 * n_blocks);
+    for (int b = 0; b < n_blocks; ++b) { tab[b] = local_start[b]; tab[n_blocks + b] = global_start[b]; }
+    long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, tab.size() * 8));
+    HIP_TRY(hipMemcpy(d, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+    if (idx->d_blk) idx->blk_retired.push_back(idx->d_blk);    // searches already enqueued keep reading the table they were given
+    idx->d_blk = d;
+    idx->blk_local.assign(local_start, local_start + n_blocks);
+    idx->blk_global.assign(global_start, global_start + n_blocks);
+    idx->id_base = global_start[0];
     return CMR_OK;
 }
 
@@ -1154,8 +1232,9 @@ int32_t cmr_index_sorted_scores(cmr_index_t* idx, const float* q, int32_t nq, in
     for (int qi = 0; qi < nq; ++qi) {
         rc = scores_enqueue(idx, ws, (const float*)ws->d_q.p + (size_t)qi * idx->dim, 1, (float*)ws->d_out.p, n);
         if (rc) { (void)hipStreamSynchronize(s); return rc; }
-        HIP_TRY(cmr_launch_sort_scores((const float*)ws->d_out.p, n, idx->id_base, ws->d_cand.p, (int64_t*)ws->d_ids.p,
+        HIP_TRY(cmr_launch_sort_scores((const float*)ws->d_out.p, n, kernel_id_base(idx), ws->d_cand.p, (int64_t*)ws->d_ids.p,
                                        (float*)ws->d_scores.p, s));
+        { int rc_ = remap_ids_enqueue(idx, (int64_t*)ws->d_ids.p, n, s); if (rc_) { (void)hipStreamSynchronize(s); return rc_; } }
         HIP_TRY(hipMemcpyAsync(out_ids + (size_t)qi * n, ws->d_ids.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(out_scores + (size_t)qi * n, ws->d_scores.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));     // staging buffers are reused by the next query
@@ -1178,6 +1257,16 @@ int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const in
     if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
     struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
     hipStream_t s = ws->stream;
+    // a shard with a block table: candidates come in as global ids, the kernel works on local rows (base 0), its output
+    // ids are translated back on the stream
+    std::vector<int64_t> local_cand;
+    const bool blocks = idx->blk_local.size() > 1;
+    if (blocks) {
+        local_cand.resize((size_t)nq * n_cand);
+        for (size_t i = 0; i < local_cand.size(); ++i) local_cand[i] = to_local_row(idx, cand[i]);
+        cand = local_cand.data();
+    }
+    const long long base = kernel_id_base(idx);
     {   // few queries (the exact re-scorer behind a top-100 search): candidates + queries go down in ONE copy from the pinned
         // buffer (the kernel re-reads each query once per candidate: not across the link), the results are written straight
         // into its mapped half — one copy, one launch, one sync instead of two copies each way
@@ -1192,9 +1281,10 @@ int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const in
             memcpy(h + o_in, cand, (size_t)nq * n_cand * 8);
             memcpy(h + o_in + c_bytes, q, q_bytes);
             HIP_TRY(hipMemcpyAsync(ws->d_cand.p, h + o_in, c_bytes + q_bytes, hipMemcpyHostToDevice, s));
-            HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, idx->id_base,
+            HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, base,
                                        (const float*)((const char*)ws->d_cand.p + c_bytes), nq, (const int64_t*)ws->d_cand.p, n_cand, k,
                                        (int64_t*)(d + o_ids), (float*)(d + o_sc), s));
+            { int rc_ = remap_ids_enqueue(idx, (int64_t*)(d + o_ids), (long long)nq * k, s); if (rc_) { (void)hipStreamSynchronize(s); return rc_; } }
             HIP_TRY(hipStreamSynchronize(s));
             memcpy(out_ids, h + o_ids, i_bytes);
             memcpy(out_scores, h + o_sc, s_bytes);
@@ -1207,8 +1297,9 @@ int32_t cmr_index_rescore(cmr_index_t* idx, const float* q, int32_t nq, const in
     HIP_TRY(ws->d_scores.ensure((size_t)nq * k * 4));
     HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(ws->d_cand.p, cand, (size_t)nq * n_cand * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, idx->id_base, (const float*)ws->d_q.p, nq,
+    HIP_TRY(cmr_launch_rescore(idx->dtype, idx->corpus, idx->shadow, idx->dim, idx->dpad, idx->n, base, (const float*)ws->d_q.p, nq,
                                (const int64_t*)ws->d_cand.p, n_cand, k, (int64_t*)ws->d_ids.p, (float*)ws->d_scores.p, s));
+    { int rc_ = remap_ids_enqueue(idx, (int64_t*)ws->d_ids.p, (long long)nq * k, s); if (rc_) { (void)hipStreamSynchronize(s); return rc_; } }
     HIP_TRY(hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1227,8 +1318,14 @@ int32_t cmr_index_get_rows(cmr_index_t* idx, const int64_t* ids, int64_t n, floa
     hipStream_t s = ws->stream;
     HIP_TRY(ws->d_cand.ensure((size_t)n * 8));
     HIP_TRY(ws->d_out.ensure((size_t)n * idx->dim * 4));
+    std::vector<int64_t> local_ids;
+    if (idx->blk_local.size() > 1) {      // global ids -> local rows through the block table (a row this shard does not hold: -1, as an id outside [base, base + n))
+        local_ids.resize((size_t)n);
+        for (int64_t i = 0; i < n; ++i) local_ids[i] = to_local_row(idx, ids[i]);
+        ids = local_ids.data();
+    }
     HIP_TRY(hipMemcpyAsync(ws->d_cand.p, ids, (size_t)n * 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(cmr_launch_gather_rows(idx->dtype, idx->corpus, idx->dim, idx->dpad, idx->n, idx->id_base, (const int64_t*)ws->d_cand.p, n,
+    HIP_TRY(cmr_launch_gather_rows(idx->dtype, idx->corpus, idx->dim, idx->dpad, idx->n, kernel_id_base(idx), (const int64_t*)ws->d_cand.p, n,
                                    (float*)ws->d_out.p, s));
     HIP_TRY(hipMemcpyAsync(out, ws->d_out.p, (size_t)n * idx->dim * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

@@ -1010,6 +1010,28 @@ hipError_t cmr_launch_sort_scores(const float* scores, long long n, long long id
 }
 
 // ------------------------------------------------------------------------------------------
+// Shard-local row -> global id through the shard's block table (a row shard that took incremental appends holds several
+// runs of consecutive global ids: block b = local rows [local0[b], local0[b+1]) = global ids global0[b] + ...).
+// tab = [local0[0..nb) | global0[0..nb)], local0 ascending, local0[0] = 0.  Negative ids (empty slots) pass through.
+__global__ __launch_bounds__(256) void remap_ids_kernel(int64_t* __restrict__ ids, long long n, const long long* __restrict__ tab, int nb) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = ids[i];
+    if (r < 0) return;
+    int lo = 0, hi = nb - 1;                 // last block with local0 <= r
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    ids[i] = r - tab[lo] + tab[nb + lo];
+}
+hipError_t cmr_launch_remap_ids(int64_t* ids, long long n, const long long* tab, int nb, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(remap_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids, n, tab, nb);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // Row access in the panel-major layout.
 template <int DT>
 __device__ __forceinline__ float cmr_load_elem(const unsigned char* corpus, int ks_total, long long row, int kidx) {

@@ -95,6 +95,8 @@ hipError_t cmr_launch_rescore(int dtype, const void* corpus, const float* shadow
 // gather rows as fp32
 hipError_t cmr_launch_gather_rows(int dtype, const void* corpus, int dim, int dpad, long long nrows, long long id_base,
                                   const int64_t* ids, long long n, float* out, hipStream_t s);
+// ids[i] (shard-local row, < 0 = empty) -> global id through the block table [local0[nb] | global0[nb]] (device)
+hipError_t cmr_launch_remap_ids(int64_t* ids, long long n, const long long* tab, int nb, hipStream_t s);
 // masked mean-pool + L2 norm
 hipError_t cmr_launch_pool(const void* hidden, int hidden_dtype, const int64_t* mask, int b, int l, int d,
                            int normalize, float* partial, float* out, int splits, hipStream_t s);

@@ -28,6 +28,7 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl* rccl() {
@@ -48,6 +49,7 @@ Rccl* rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
         r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) r.h = nullptr;
     });
     return r.h ? &r : nullptr;
@@ -156,6 +158,19 @@ int32_t cmr_comm_create(int32_t world, int32_t rank, const uint8_t* id128, int32
     ncclResult_t rc = r->CommInitRank(&c->nccl, world, id, rank);
     if (rc != ncclSuccess) { delete c; return cmr_fail(CMR_ERR_HIP, "ncclCommInitRank: %s", r->GetErrorString ? r->GetErrorString(rc) : "error"); }
     *out = c;
+    return CMR_OK;
+}
+
+int32_t cmr_comm_info(cmr_comm_t* c, int32_t* world, int32_t* rank, int32_t* rccl_ranks) {
+    if (!c) return cmr_fail(CMR_ERR_INVALID, "NULL communicator");
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    if (rccl_ranks) {
+        *rccl_ranks = 0;
+        Rccl* r = rccl();
+        int n = 0;
+        if (r && r->CommCount && c->nccl && r->CommCount(c->nccl, &n) == ncclSuccess) *rccl_ranks = n;
+    }
     return CMR_OK;
 }
 

@@ -18,6 +18,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "../../include/comorag_hip.h"
@@ -29,6 +31,18 @@ int cmr_fail(int code, const char* fmt, ...);                                   
 int cmr_index_scores_to_device(cmr_index_t* idx, const float* q_host, float** scores_dev, long long* n, void** stream);
 int cmr_index_scores_release(cmr_index_t* idx);
 
+struct PprScratch {
+    double *reset = nullptr, *x = nullptr, *y = nullptr, *red = nullptr, *out = nullptr;
+    float2* mm = nullptr;              // per-block (min, max) partials of the raw scores
+    int* seed_v = nullptr;
+    double* seed_w = nullptr;
+    long long seed_cap = 0, out_cap = 0;
+    void release() {
+        for (void* p : {(void*)reset, (void*)x, (void*)y, (void*)red, (void*)out, (void*)mm, (void*)seed_v, (void*)seed_w})
+            if (p) (void)hipFree(p);
+    }
+};
+
 struct cmr_graph {
     int device = 0;
     long long nv = 0, ne = 0;          // vertices, directed CSR entries (2 x undirected edges, self-loops once)
@@ -39,11 +53,13 @@ struct cmr_graph {
     long long n_dangling = 0;
     int* vertex_of_row = nullptr;      // passage row -> vertex
     long long n_rows = 0;
-    double *reset = nullptr, *x = nullptr, *y = nullptr, *red = nullptr, *out = nullptr;
-    float2* mm = nullptr;              // per-block (min, max) partials of the raw scores
-    int* seed_v = nullptr;
-    double* seed_w = nullptr;
-    long long seed_cap = 0;
+    // Per-call scratch.  ComoRAG runs graph_search_with_fact_entities from up to 16 threads at once (ComoRAG.try_answer's
+    // ThreadPoolExecutor, ComoRAG.py:437) and ctypes releases the GIL: every call takes its own set of vectors from this
+    // pool (grown on demand, one set per concurrent caller), so concurrent queries on one graph never share a reset / x / y.
+    std::mutex mu;                     // guards the pool and the passage-vertex map's replacement
+    std::vector<PprScratch*> pool;
+    int users = 0;                     // calls in flight (cmr_graph_set_passage_vertices waits for none)
+    std::condition_variable idle;
 };
 
 #define PPR_TRY(expr)                                                                                                  \
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(PPR_T) void ppr_scatter_kernel(const float* __restr
 
 __global__ __launch_bounds__(PPR_T) void ppr_seed_kernel(const int* __restrict__ v, const double* __restrict__ w, long long n, double* __restrict__ reset) {
     const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
-    if (i < n) reset[v[i]] += w[i];          // phrase vertices and passage vertices are disjoint sets (ComoRAG.py:1045)
+    if (i < n) reset[v[i]] += w[i];          // seed vertices are distinct here: the host sums duplicates first (merge_seeds), in input order
 }
 
 // reset <- max(reset, 0) with NaN -> 0 (ComoRAG.py:1090); partial sums per block
@@ -155,36 +171,92 @@ __global__ __launch_bounds__(PPR_T) void ppr_gather_kernel(const double* __restr
 
 static unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + PPR_T - 1) / PPR_T); }
 
-// reset (device, raw) -> normalised -> power iteration -> x holds the stationary vector
-static int ppr_iterate(cmr_graph* g, double damping, double tol, int max_iter, hipStream_t s, int* iters_out) {
+// One set of per-call vectors out of the graph's pool (allocated on first use, one per concurrent caller).
+static int scratch_acquire(cmr_graph* g, PprScratch** out) {
+    *out = nullptr;
+    PprScratch* sc = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (!g->pool.empty()) { sc = g->pool.back(); g->pool.pop_back(); }
+        g->users++;
+    }
+    auto give_up = [&](hipError_t e, const char* what) {
+        if (sc) { sc->release(); delete sc; }
+        { std::lock_guard<std::mutex> lk(g->mu); g->users--; }
+        g->idle.notify_all();
+        return cmr_fail(e == hipErrorOutOfMemory ? CMR_ERR_OOM : CMR_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    };
+    if (!sc) {
+        sc = new PprScratch();
+        hipError_t e = hipMalloc((void**)&sc->reset, (size_t)g->nv * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->x, (size_t)g->nv * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->y, (size_t)g->nv * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->red, (PPR_RED_BLOCKS + 8) * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&sc->mm, PPR_RED_BLOCKS * sizeof(float2));
+        if (e != hipSuccess) return give_up(e, "PPR scratch");
+    }
+    if (sc->out_cap < g->n_rows) {
+        if (sc->out) (void)hipFree(sc->out);
+        sc->out = nullptr; sc->out_cap = 0;
+        hipError_t e = hipMalloc((void**)&sc->out, std::max<size_t>((size_t)g->n_rows * 8, 8));
+        if (e != hipSuccess) return give_up(e, "PPR output scratch");
+        sc->out_cap = g->n_rows;
+    }
+    *out = sc;
+    return CMR_OK;
+}
+static void scratch_release(cmr_graph* g, PprScratch* sc) {
+    { std::lock_guard<std::mutex> lk(g->mu); g->pool.push_back(sc); g->users--; }
+    g->idle.notify_all();
+}
+struct ScratchGuard {
+    cmr_graph* g; PprScratch* sc;
+    ~ScratchGuard() { if (sc) scratch_release(g, sc); }
+};
+
+// reset (device, raw) -> normalised -> power iteration -> *result holds the stationary vector (sc->x or sc->y)
+static int ppr_iterate(cmr_graph* g, PprScratch* sc, double damping, double tol, int max_iter, hipStream_t s, int* iters_out, double** result) {
     const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(g->nv));
-    hipLaunchKernelGGL(ppr_clean_sum_kernel, dim3(nparts), dim3(PPR_T), 0, s, g->reset, g->nv, g->red);
-    hipLaunchKernelGGL(ppr_normalise_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, g->reset, g->x, g->nv, g->red, nparts);
+    hipLaunchKernelGGL(ppr_clean_sum_kernel, dim3(nparts), dim3(PPR_T), 0, s, sc->reset, g->nv, sc->red);
+    hipLaunchKernelGGL(ppr_normalise_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, sc->reset, sc->x, g->nv, sc->red, nparts);
     int iters = (int)std::ceil(std::log(std::max(tol, 1e-300) / 2.0) / std::log(std::min(std::max(damping, 1e-12), 1.0 - 1e-12)));
     iters = std::max(1, std::min(iters, max_iter > 0 ? max_iter : 1000));
     if (damping <= 0.0) iters = 1;
-    double *x = g->x, *y = g->y;
+    double *x = sc->x, *y = sc->y;
     for (int it = 0; it < iters; ++it) {
-        if (g->n_dangling) hipLaunchKernelGGL(ppr_dangling_kernel, dim3(1), dim3(PPR_T), 0, s, x, g->dangling, g->n_dangling, g->red + PPR_RED_BLOCKS);
-        hipLaunchKernelGGL(ppr_step_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, x, g->reset,
-                           g->n_dangling ? g->red + PPR_RED_BLOCKS : nullptr, damping, g->nv, y);
+        if (g->n_dangling) hipLaunchKernelGGL(ppr_dangling_kernel, dim3(1), dim3(PPR_T), 0, s, x, g->dangling, g->n_dangling, sc->red + PPR_RED_BLOCKS);
+        hipLaunchKernelGGL(ppr_step_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, x, sc->reset,
+                           g->n_dangling ? sc->red + PPR_RED_BLOCKS : nullptr, damping, g->nv, y);
         std::swap(x, y);
     }
-    if (x != g->x) std::swap(g->x, g->y);          // g->x = result
+    *result = x;
     if (iters_out) *iters_out = iters;
     PPR_TRY(hipGetLastError());
     return CMR_OK;
 }
 
-static int ensure_seeds(cmr_graph* g, long long n) {
-    if (n <= g->seed_cap) return CMR_OK;
-    if (g->seed_v) PPR_TRY(hipFree(g->seed_v));
-    if (g->seed_w) PPR_TRY(hipFree(g->seed_w));
-    g->seed_v = nullptr; g->seed_w = nullptr; g->seed_cap = 0;
-    PPR_TRY(hipMalloc((void**)&g->seed_v, (size_t)n * 4));
-    PPR_TRY(hipMalloc((void**)&g->seed_w, (size_t)n * 8));
-    g->seed_cap = n;
+static int ensure_seeds(PprScratch* sc, long long n) {
+    if (n <= sc->seed_cap) return CMR_OK;
+    if (sc->seed_v) PPR_TRY(hipFree(sc->seed_v));
+    if (sc->seed_w) PPR_TRY(hipFree(sc->seed_w));
+    sc->seed_v = nullptr; sc->seed_w = nullptr; sc->seed_cap = 0;
+    PPR_TRY(hipMalloc((void**)&sc->seed_v, (size_t)n * 4));
+    PPR_TRY(hipMalloc((void**)&sc->seed_w, (size_t)n * 8));
+    sc->seed_cap = n;
     return CMR_OK;
+}
+
+// Duplicate seed vertices are summed on the host, in input order (numpy's `w[v] += x` in a loop, ComoRAG.py:1019-1021):
+// the seed kernel then adds every vertex once — no lost update, no atomics, one fixed summation order.
+static void merge_seeds(const int32_t* v, const double* w, int n, std::vector<int>& ov, std::vector<double>& ow) {
+    std::vector<std::pair<int, int>> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[i] = {v[i], i};
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first < b.first; });
+    ov.clear(); ow.clear();
+    for (int i = 0; i < n; ++i) {
+        if (!ov.empty() && ov.back() == order[i].first) ow.back() += w[order[i].second];
+        else { ov.push_back(order[i].first); ow.push_back(w[order[i].second]); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------ C-ABI
@@ -241,11 +313,6 @@ int32_t cmr_graph_create(int32_t device_id, int64_t n_vertices, int64_t n_edges,
     if (e == hipSuccess) e = up((void**)&g->col, col.data(), (size_t)ne * 4);
     if (e == hipSuccess) e = up((void**)&g->wnorm, wn.data(), (size_t)ne * 8);
     if (e == hipSuccess) e = up((void**)&g->dangling, dang.data(), dang.size() * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->reset, (size_t)n_vertices * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->x, (size_t)n_vertices * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->y, (size_t)n_vertices * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->red, (PPR_RED_BLOCKS + 8) * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&g->mm, PPR_RED_BLOCKS * sizeof(float2));
     if (e != hipSuccess) { cmr_graph_destroy(g); return cmr_fail(e == hipErrorOutOfMemory ? CMR_ERR_OOM : CMR_ERR_HIP, "graph upload: %s", hipGetErrorString(e)); }
     *out = g;
     return CMR_OK;
@@ -255,9 +322,9 @@ int32_t cmr_graph_destroy(cmr_graph_t* g) {
     if (!g) return CMR_OK;
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
-    for (void* p : {(void*)g->rowptr, (void*)g->col, (void*)g->wnorm, (void*)g->dangling, (void*)g->vertex_of_row, (void*)g->reset, (void*)g->x, (void*)g->y,
-                    (void*)g->red, (void*)g->out, (void*)g->seed_v, (void*)g->seed_w, (void*)g->mm})
+    for (void* p : {(void*)g->rowptr, (void*)g->col, (void*)g->wnorm, (void*)g->dangling, (void*)g->vertex_of_row})
         if (p) (void)hipFree(p);
+    for (PprScratch* sc : g->pool) { sc->release(); delete sc; }
     delete g;
     return CMR_OK;
 }
@@ -267,12 +334,11 @@ int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_
     for (int64_t i = 0; i < n_rows; ++i)
         if (vertex_of_row[i] < 0 || vertex_of_row[i] >= g->nv) return cmr_fail(CMR_ERR_INVALID, "row %lld maps to vertex %d outside the graph", (long long)i, vertex_of_row[i]);
     PPR_TRY(hipSetDevice(g->device));
-    PPR_TRY(hipDeviceSynchronize());
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->idle.wait(lk, [&] { return g->users == 0; });       // no query may be reading the old map
     if (g->vertex_of_row) PPR_TRY(hipFree(g->vertex_of_row));
-    if (g->out) PPR_TRY(hipFree(g->out));
-    g->vertex_of_row = nullptr; g->out = nullptr; g->n_rows = 0;
+    g->vertex_of_row = nullptr; g->n_rows = 0;
     PPR_TRY(hipMalloc((void**)&g->vertex_of_row, std::max<size_t>((size_t)n_rows * 4, 8)));
-    PPR_TRY(hipMalloc((void**)&g->out, std::max<size_t>((size_t)n_rows * 8, 8)));
     if (n_rows) PPR_TRY(hipMemcpy(g->vertex_of_row, vertex_of_row, (size_t)n_rows * 4, hipMemcpyHostToDevice));
     g->n_rows = n_rows;
     return CMR_OK;
@@ -281,11 +347,23 @@ int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_
 int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, double tol, int32_t max_iter, double* out_scores, int32_t* iters) {
     if (!g || !reset || !out_scores) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
     PPR_TRY(hipSetDevice(g->device));
-    PPR_TRY(hipMemcpyAsync(g->reset, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, nullptr));
-    int rc = ppr_iterate(g, damping, tol, max_iter, nullptr, iters);
+    PprScratch* sc = nullptr;
+    int rc = scratch_acquire(g, &sc);
     if (rc) return rc;
-    PPR_TRY(hipMemcpy(out_scores, g->x, (size_t)g->nv * 8, hipMemcpyDeviceToHost));
-    return CMR_OK;
+    ScratchGuard guard{g, sc};
+    hipStream_t s = hipStreamPerThread;                     // concurrent callers do not queue behind each other on the null stream
+    auto body = [&]() -> int {
+        PPR_TRY(hipMemcpyAsync(sc->reset, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, s));
+        double* res = nullptr;
+        int rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
+        if (rc_) return rc_;
+        PPR_TRY(hipMemcpyAsync(out_scores, res, (size_t)g->nv * 8, hipMemcpyDeviceToHost, s));
+        return CMR_OK;
+    };
+    rc = body();
+    const hipError_t es = hipStreamSynchronize(s);          // also on error paths: nothing may still use the scratch when it goes back
+    if (!rc && es != hipSuccess) rc = cmr_fail(CMR_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+    return rc;
 }
 
 int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, const int32_t* seed_vertices, const double* seed_weights, int32_t n_seeds,
@@ -295,36 +373,51 @@ int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, cons
     if (!g->vertex_of_row) return cmr_fail(CMR_ERR_INVALID, "cmr_graph_set_passage_vertices was not called");
     for (int i = 0; i < n_seeds; ++i)
         if (seed_vertices[i] < 0 || seed_vertices[i] >= g->nv) return cmr_fail(CMR_ERR_INVALID, "seed vertex %d outside the graph", seed_vertices[i]);
+    std::vector<int> sv;
+    std::vector<double> sw;
+    merge_seeds(seed_vertices, seed_weights, n_seeds, sv, sw);
+    const int ns = (int)sv.size();
+    PprScratch* sc = nullptr;
+    int rc = scratch_acquire(g, &sc);
+    if (rc) return rc;
+    ScratchGuard guard{g, sc};
     float* scores = nullptr;
     long long n = 0;
     void* st = nullptr;
-    int rc = cmr_index_scores_to_device(idx, q_f32, &scores, &n, &st);       // scan; the scores stay in HBM (index lock held until release)
+    rc = cmr_index_scores_to_device(idx, q_f32, &scores, &n, &st);       // scan; the scores stay in HBM (index lock held until release)
     if (rc) return rc;
-    struct Rel { cmr_index_t* i; bool armed = true; ~Rel() { if (armed) (void)cmr_index_scores_release(i); } } rel{idx};
-    if (n != g->n_rows) return cmr_fail(CMR_ERR_INVALID, "index has %lld rows, the passage-vertex map %lld", n, g->n_rows);
     hipStream_t s = (hipStream_t)st;
-    rc = ensure_seeds(g, std::max(n_seeds, 1));
+    auto body = [&]() -> int {
+        if (n != g->n_rows) return cmr_fail(CMR_ERR_INVALID, "index has %lld rows, the passage-vertex map %lld", n, g->n_rows);
+        int rc_ = ensure_seeds(sc, std::max(ns, 1));
+        if (rc_) return rc_;
+        if (ns) {
+            PPR_TRY(hipMemcpyAsync(sc->seed_v, sv.data(), (size_t)ns * 4, hipMemcpyHostToDevice, s));
+            PPR_TRY(hipMemcpyAsync(sc->seed_w, sw.data(), (size_t)ns * 8, hipMemcpyHostToDevice, s));
+        }
+        PPR_TRY(hipMemsetAsync(sc->reset, 0, (size_t)g->nv * 8, s));
+        const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(n));
+        if (n) {
+            hipLaunchKernelGGL(ppr_minmax_partial_kernel, dim3(nparts), dim3(PPR_T), 0, s, scores, n, sc->mm);
+            hipLaunchKernelGGL(ppr_scatter_kernel, dim3(blocks_for(n)), dim3(PPR_T), 0, s, scores, n, sc->mm, nparts, g->vertex_of_row, passage_node_weight, sc->reset);
+        }
+        if (ns) hipLaunchKernelGGL(ppr_seed_kernel, dim3(blocks_for(ns)), dim3(PPR_T), 0, s, sc->seed_v, sc->seed_w, (long long)ns, sc->reset);
+        double* res = nullptr;
+        rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
+        if (rc_) return rc_;
+        if (n) hipLaunchKernelGGL(ppr_gather_kernel, dim3(blocks_for(n)), dim3(PPR_T), 0, s, res, g->vertex_of_row, n, sc->out);
+        PPR_TRY(hipGetLastError());
+        PPR_TRY(hipMemcpyAsync(out_doc_scores, sc->out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        return CMR_OK;
+    };
+    rc = body();
+    // Whatever happened, the stream is drained before the workspace and the scratch go back: kernels enqueued ahead of a
+    // failing call would otherwise still be running on buffers the next caller reuses.
+    const hipError_t es = hipStreamSynchronize(s);
+    const int rc_rel = cmr_index_scores_release(idx);       // CMR_ERR_NONFINITE if the query held NaN / Inf
     if (rc) return rc;
-    if (n_seeds) {
-        PPR_TRY(hipMemcpyAsync(g->seed_v, seed_vertices, (size_t)n_seeds * 4, hipMemcpyHostToDevice, s));
-        PPR_TRY(hipMemcpyAsync(g->seed_w, seed_weights, (size_t)n_seeds * 8, hipMemcpyHostToDevice, s));
-    }
-    PPR_TRY(hipMemsetAsync(g->reset, 0, (size_t)g->nv * 8, s));
-    const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(n));
-    float2* part = g->mm;
-    if (n) {
-        hipLaunchKernelGGL(ppr_minmax_partial_kernel, dim3(nparts), dim3(PPR_T), 0, s, scores, n, part);
-        hipLaunchKernelGGL(ppr_scatter_kernel, dim3(blocks_for(n)), dim3(PPR_T), 0, s, scores, n, part, nparts, g->vertex_of_row, passage_node_weight, g->reset);
-    }
-    if (n_seeds) hipLaunchKernelGGL(ppr_seed_kernel, dim3(blocks_for(n_seeds)), dim3(PPR_T), 0, s, g->seed_v, g->seed_w, (long long)n_seeds, g->reset);
-    rc = ppr_iterate(g, damping, tol, max_iter, s, iters);
-    if (rc) return rc;
-    if (n) hipLaunchKernelGGL(ppr_gather_kernel, dim3(blocks_for(n)), dim3(PPR_T), 0, s, g->x, g->vertex_of_row, n, g->out);
-    PPR_TRY(hipGetLastError());
-    PPR_TRY(hipMemcpyAsync(out_doc_scores, g->out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    PPR_TRY(hipStreamSynchronize(s));
-    rel.armed = false;
-    return cmr_index_scores_release(idx);          // CMR_ERR_NONFINITE if the query held NaN / Inf
+    if (es != hipSuccess) return cmr_fail(CMR_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(es));
+    return rc_rel;
 }
 
 }  // extern "C"

@@ -114,7 +114,14 @@ class EmbeddingStore:
         (a) whole vectors without an id line, (b) a torn last vector, (c) a torn last id line.  The id lines that are
         complete AND have their vector are the store; everything behind them is cut off both files."""
         import json
-        if not (os.path.exists(self._rows_file) and os.path.exists(self._mat_file)):
+        if not os.path.exists(self._rows_file):
+            # The very first append crashed between the vectors and the id lines: whole orphan vectors and no id file.
+            # They are zero valid rows — left in place, the next append would write behind them and the following load
+            # would bind every id to an orphan vector.
+            if os.path.exists(self._mat_file):
+                os.remove(self._mat_file)
+            return False
+        if not os.path.exists(self._mat_file):
             return False
         rows, good_bytes = [], 0
         with open(self._rows_file, "rb") as f:

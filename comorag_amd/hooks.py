@@ -144,10 +144,9 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
                 key = mdhash(content=phrase, prefix="entity-")
                 vid = self.node_name_to_vertex_idx.get(key, None)
                 if vid is not None:
-                    w = fact_score
+                    phrase_weights[vid] = fact_score          # float64 slot first, THEN the division: as ComoRAG.py:1019-1021
                     if self.ent_node_to_num_chunk[key] != 0:
-                        w = w / self.ent_node_to_num_chunk[key]
-                    phrase_weights[vid] = w
+                        phrase_weights[vid] /= self.ent_node_to_num_chunk[key]
                     if phrase_weights[vid] > 0:
                         used_phrases_with_scores[phrase] = phrase_weights[vid]
                 seen.setdefault(phrase, []).append(fact_score)
@@ -155,6 +154,10 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
         if link_top_k:
             phrase_weights, linking_score_map = self.get_top_k_weights(link_top_k, phrase_weights, linking_score_map)
         q = _query_vec(self, "passage", query, "query_to_passage")
+        # ComoRAG.py:1051 `assert sum(node_weights) > 0`: the passage part sums to > 0 exactly when there are passages and a
+        # positive passage_node_weight (the best passage normalises to 1.0), so the test needs no score from the device
+        assert phrase_weights.sum() > 0 or (len(index) > 0 and passage_node_weight > 0), \
+            f'No phrases found in the graph for the given facts: {top_k_facts}'
         if hasattr(g, "passage_scores"):
             doc_scores = g.passage_scores(index, q, phrase_weights, passage_node_weight, 0.5)
         else:

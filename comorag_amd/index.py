@@ -156,6 +156,15 @@ class DenseIndex:
         """Offset added to every returned row id (global id of local row 0 of a row shard)."""
         L.check(L.lib().cmr_index_set_id_base(self._h, int(base)))
 
+    def set_id_blocks(self, local_starts, global_starts) -> None:
+        """Block table of a shard that took incremental appends: local rows [local_starts[b], local_starts[b+1]) carry the
+        global ids global_starts[b] + 0, 1, ... (cmr_index_set_id_blocks)."""
+        ls = np.ascontiguousarray(local_starts, dtype=np.int64)
+        gs = np.ascontiguousarray(global_starts, dtype=np.int64)
+        if ls.shape != gs.shape or ls.ndim != 1 or len(ls) == 0:
+            raise ValueError("local_starts / global_starts must be equally long, non-empty 1-d arrays")
+        L.check(L.lib().cmr_index_set_id_blocks(self._h, len(ls), _ptr(ls), _ptr(gs)))
+
     def pipeline_stream(self, which: int = 2):
         """The pipeline's pre / scan / post stream as a torch.cuda.ExternalStream."""
         import torch

@@ -10,6 +10,13 @@ all-gather + merge of batch i run on the index pipeline's post stream while the 
 runs on its scan stream (`search_pipelined`).  Two bindings of the same exchange:
   exchange="torch"  torch.distributed.all_gather_into_tensor between cmr_pack_candidates_dev and cmr_merge_keys_dev
   exchange="cabi"   cmr_comm_allgather_merge: RCCL called by the library itself (no torch in the data path)
+On a `gloo` group (CPU tests; two ranks sharing one GPU in the 1-GPU rehearsal of the N > 1 flow) the same packed keys
+are staged through the host around the collective.
+
+Incremental appends (`append`; BASELINE config 4 at N > 1): global ids stay dense in append order — what
+EmbeddingStore._upsert (embedding_store.py:122-128) and MemoryPool.add_node (utils/memory_utils.py:294-300) rely on —
+and an append goes to the currently shortest shard, so a shard holds several runs of consecutive global ids; the host-side
+table of those runs (`blocks`) is mirrored into the library with cmr_index_set_id_blocks.
 """
 from __future__ import annotations
 
@@ -49,9 +56,93 @@ class ShardedIndex:
             index.set_id_base(self.base)        # the library returns global ids from here on
         self._post = None
         self._bufs = {}
+        # layout (host-side base table): this shard's runs of consecutive global ids [(local_start, global_start)], and —
+        # once `sync_layout` ran — every shard's row count and the global row count, identical on every rank
+        self.blocks = [(0, self.base)]
+        self.sizes = None
+        self.total = None
+        self._owns_local = True
 
     def __len__(self):
         return len(self.local)
+
+    # ---------------------------------------------------------------- layout / incremental append
+    def sync_layout(self):
+        """Collective, once after the bulk build: every rank learns every shard's (base, rows).  The bulk layout must be the
+        contiguous one of `shard_bounds` (rank r starts where rank r-1 ends)."""
+        mine = (self.base, len(self.local))
+        if self.world > 1:
+            import torch.distributed as dist
+            box = [None] * self.world
+            dist.all_gather_object(box, mine, group=self.group)
+        else:
+            box = [mine]
+        at = box[0][0]
+        for r, (b, n) in enumerate(box):
+            if b != at:
+                raise ValueError(f"shard {r} starts at global id {b}, expected {at}: bulk shards must be contiguous row blocks")
+            at += n
+        self.sizes = [n for _, n in box]
+        self.total = at
+        return self
+
+    def _route(self, m: int, block_rows: int):
+        """[(shard, n rows)] for m appended rows: chunks of <= block_rows, each to the shortest shard at that moment (lowest
+        rank on ties) — deterministic, so every rank computes the same routing from the same table."""
+        sizes = list(self.sizes)
+        out = []
+        while m > 0:
+            n = min(m, block_rows)
+            t = min(range(self.world), key=lambda r: (sizes[r], r))
+            out.append((t, n))
+            sizes[t] += n
+            m -= n
+        return out
+
+    def append(self, rows, block_rows: int = 8192) -> "np.ndarray":
+        """Collective append of `rows` [m, dim] (numpy; every rank passes the same rows, only the owner of a chunk uploads
+        it).  The rows get the global ids total .. total + m - 1 in order, exactly as one index would number them; returns
+        those ids.  Chunks of `block_rows` go to the currently shortest shard."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        if self.sizes is None:
+            self.sync_layout()
+        m = rows.shape[0]
+        first = self.total
+        at = 0
+        changed = False
+        for shard, n in self._route(m, block_rows):
+            if shard == self.rank:
+                local_at = len(self.local)
+                self.local.append(rows[at:at + n])
+                l0, g0 = self.blocks[-1]
+                if g0 + (local_at - l0) != self.total:      # not a continuation of this shard's last run: a new block
+                    if local_at == l0:                      # (the last run is still empty: it simply starts elsewhere)
+                        self.blocks[-1] = (local_at, self.total)
+                    else:
+                        self.blocks.append((local_at, self.total))
+                    changed = True
+            self.sizes[shard] += n
+            self.total += n
+            at += n
+        if changed:
+            self._push_blocks()
+        return np.arange(first, first + m, dtype=np.int64)
+
+    def _push_blocks(self):
+        self.base = self.blocks[0][1]
+        if hasattr(self.local, "set_id_blocks"):
+            self.local.set_id_blocks([b[0] for b in self.blocks], [b[1] for b in self.blocks])
+
+    def _to_global(self, ids: np.ndarray) -> np.ndarray:
+        """Shard-local rows -> global ids through the block table (numpy twin of the library's remap; used where a stand-in
+        replaces the HIP scan)."""
+        ids = np.asarray(ids, np.int64)
+        ls = np.array([b[0] for b in self.blocks], np.int64)
+        gs = np.array([b[1] for b in self.blocks], np.int64)
+        b = np.clip(np.searchsorted(ls, ids, side="right") - 1, 0, len(ls) - 1)
+        return np.where(ids >= 0, ids - ls[b] + gs[b], -1)
 
     # ---------------------------------------------------------------- host (numpy) path
     def search(self, q: np.ndarray, k: int, local_search: Optional[Callable] = None):
@@ -62,7 +153,7 @@ class ShardedIndex:
         from .index import merge_topk
         if local_search is not None:            # CPU-only tests: shard-local ids from the stand-in
             ids, sc = local_search(q, k)
-            ids = np.where(ids >= 0, ids + self.base, -1)
+            ids = self._to_global(ids)
         else:                                   # HIP scan: ids are already global (cmr_index_set_id_base)
             ids, sc = self.local.search(q, k, with_minmax=False)[:2]
         nq = q.shape[0]
@@ -134,7 +225,15 @@ class ShardedIndex:
                 else:
                     L.check(L.lib().cmr_pack_candidates_dev(C.c_void_p(b["ids"].data_ptr()), C.c_void_p(b["sc"].data_ptr()), nq * k,
                                                             C.c_void_p(b["keys"].data_ptr()), ps))
-                    dist.all_gather_into_tensor(b["g_keys"], b["keys"], group=self.group)     # the one collective of the batch
+                    if self.world > 1 and dist.get_backend(self.group) == "gloo":
+                        # ranks sharing one GPU (the 1-GPU rehearsal of the N > 1 flow) or a CPU collective: the packed keys go
+                        # through the host around the all-gather — same keys, same single collective, same merge kernel
+                        hk = b["keys"].cpu()                                  # synchronises the post stream
+                        hg = torch.empty((self.world * nq, k), dtype=torch.int64)
+                        dist.all_gather_into_tensor(hg, hk, group=self.group)
+                        b["g_keys"].copy_(hg)
+                    else:
+                        dist.all_gather_into_tensor(b["g_keys"], b["keys"], group=self.group)     # the one collective of the batch
                     if evs: evs[1].record(self._post)
                     L.check(L.lib().cmr_merge_keys_dev(C.c_void_p(b["g_keys"].data_ptr()), self.world, nq, k,
                                                        C.c_void_p(b["o_ids"].data_ptr()), C.c_void_p(b["o_sc"].data_ptr()), ps))
@@ -172,7 +271,25 @@ class ShardedIndex:
         if self._comm is not None:
             L.lib().cmr_comm_destroy(self._comm)
             self._comm = None
-        self.local.close()
+        if self._owns_local:
+            self.local.close()
+
+    def comm_info(self) -> dict:
+        """(world, rank, ranks RCCL itself reports) of the library's own communicator."""
+        import ctypes as C
+        w, r, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(L.lib().cmr_comm_info(self.comm(), C.byref(w), C.byref(r), C.byref(n)))
+        return {"world": w.value, "rank": r.value, "rccl_ranks_seen": n.value}
+
+    def view(self, exchange: str, timing: bool = False) -> "ShardedIndex":
+        """A second handle on the SAME local shard with the other exchange binding (bench.py gives both bindings hardware
+        time: B = 64 through one, B = 256 through the other).  Closing the view leaves the shard alone."""
+        v = ShardedIndex(self.dim, self.dtype, device=self.device, rank=self.rank, world=self.world, group=self.group, base=self.base,
+                         index=_Borrowed(self.local), force_exchange=self.exchange and self.world == 1, exchange=exchange, timing=timing)
+        v.local = self.local
+        v.blocks, v.sizes, v.total = self.blocks, self.sizes, self.total
+        v._owns_local = False
+        return v
 
     def exchange_times_ms(self):
         """[(all-gather ms, merge ms)] of the batches recorded with timing=True (for the 'cabi' binding the first number
@@ -204,6 +321,16 @@ def unpack_candidates(keys: np.ndarray):
     ids = np.where(keys == 0, np.int64(-1), (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int64))
     sc = np.where(keys == 0, np.float32(-np.inf), u.view(np.float32))
     return ids, sc.astype(np.float32)
+
+
+class _Borrowed:
+    """Placeholder handed to ShardedIndex.__init__ by `view` (no set_id_base: the shard's ids are already set up)."""
+
+    def __init__(self, index):
+        self._i = index
+
+    def __len__(self):
+        return len(self._i)
 
 
 class _Done:

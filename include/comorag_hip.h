@@ -20,7 +20,8 @@
  *    the _dev and pipelined calls cannot report them without a sync: their outputs are then
  *    unspecified and cmr_index_query_status() tells, after the fact, that it happened.
  *  - handles are opaque; destroy(NULL) is a no-op.  All functions are thread-safe: searches on
- *    one index run concurrently (shared lock), append/destroy are exclusive.
+ *    one index run concurrently (shared lock), append/destroy are exclusive; concurrent
+ *    cmr_graph_ppr / cmr_index_ppr calls on one graph each take their own scratch vectors.
  *  - there is NO CPU fallback: without a visible gfx950 device every compute call fails with
  *    CMR_ERR_NO_DEVICE.
  *
@@ -130,6 +131,14 @@ int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_f32_dev, int
 /* Row-shard support: every row id returned by the search entry points is offset by `base` (the
  * global id of local row 0), so per-shard candidates can be all-gathered and merged as they are.  */
 int32_t cmr_index_set_id_base(cmr_index_t* idx, int64_t base);
+/* The same for a shard that takes INCREMENTAL appends (BASELINE config 4 at N > 1): global ids stay dense in append order
+ * (embedding_store.py:122-128, utils/memory_utils.py:294-300), an append goes to the currently shortest shard, so a shard
+ * holds several runs ("blocks") of consecutive global ids: local rows [local_start[b], local_start[b+1]) are global ids
+ * global_start[b] + 0, 1, ...  (local_start[0] = 0; both arrays ascending; the last block is open-ended and grows with
+ * cmr_index_append).  Every id the search entry points return is translated through the table (one extra tiny launch
+ * when there is more than one block), cmr_index_rescore / cmr_index_get_rows translate the ids they are given.  Global
+ * ids must stay < 2^32 - 1 (the packed candidate exchange carries 32-bit rows): checked here and by append.            */
+int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_t* local_start, const int64_t* global_start);
 /* The pipeline's streams (which = 0 pre-phase, 1 main scans, 2 candidate merges / outputs) as
  * hipStream_t.  Work enqueued on stream 2 after a pipelined call is ordered after that call's
  * outputs and before the next use of the same output buffers (the RCCL exchange goes there).     */
@@ -227,6 +236,9 @@ int32_t cmr_merge_keys_dev(const uint64_t* keys_dev /*[n_shards][nq][k]*/, int32
 int32_t cmr_comm_unique_id(uint8_t* out_id128);
 int32_t cmr_comm_create(int32_t world, int32_t rank, const uint8_t* id128, int32_t device_id, cmr_comm_t** out);
 int32_t cmr_comm_destroy(cmr_comm_t* comm);
+/* what the communicator was created with, and the rank count RCCL itself reports (ncclCommCount; 0 if unavailable) —
+ * bench.py prints it so a multi-GPU line shows that the collective really spanned N ranks                              */
+int32_t cmr_comm_info(cmr_comm_t* comm, int32_t* world, int32_t* rank, int32_t* rccl_ranks);
 int32_t cmr_comm_allgather_merge(cmr_comm_t* comm, const int64_t* ids_dev, const float* scores_dev, int32_t nq, int32_t k,
                                  int64_t* out_ids_dev, float* out_scores_dev, void* stream);
 

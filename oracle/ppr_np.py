@@ -6,13 +6,18 @@ TEST INFRASTRUCTURE ONLY (see oracle/retrieval_np.py header).  Follows
   src/comorag/ComoRAG.py:1086-1105  run_ppr: reset[nan | < 0] = 0; graph.personalized_pagerank(damping=0.5, directed=False,
                                     weights='weight', reset=reset, implementation='prpack'); doc_scores = pagerank[passage_node_idxs];
                                     argsort descending.
-Pinning: python-igraph (and with it prpack) is ABSENT from this image and the reference ships no PPR fixture, so the pin is
-constructed: `personalized_pagerank` solves the defining linear system x = d (P^T + r 1_dangling^T) x + (1 - d) r directly
-(numpy.linalg.solve — not a power iteration, so it is independent of the device algorithm), and tests/test_ppr.py checks
-it against closed forms (two vertices: x = (1/(1+d), d/(1+d)); a star; an isolated seed).  The conventions taken from
-igraph's documentation of personalized_pagerank / PRPACK: the reset vector is normalised to sum 1; a walker leaves vertex
-i along edge (i, j) with probability w_ij / strength(i), an undirected edge serving both directions; vertices without
-edges ('dangling') restart according to the reset distribution.
+Pinning: python-igraph (and with it prpack) is ABSENT from this image and the reference ships no PPR fixture.
+`personalized_pagerank` solves the defining linear system x = d (P^T + r 1_dangling^T) x + (1 - d) r directly
+(numpy.linalg.solve — not a power iteration, so it is independent of the device algorithm).  tests/test_ppr.py pins it
+(1) to closed forms (two vertices: x = (1/(1+d), d/(1+d)); a star; an isolated seed) and (2) to a THIRD-PARTY
+implementation that is in the image: networkx 3.4.2 `pagerank(G, alpha=d, personalization=r, weight='weight',
+dangling=r)` on random weighted graphs with isolated vertices, seeds on isolated vertices and negative / NaN reset entries
+(agreement 1e-12).  The conventions are those igraph documents for igraph_personalized_pagerank with the PRPACK solver
+(the reference pins igraph==0.11.8 / python-igraph==0.11.8, requirements.txt:56,138 — igraph C core 0.10): the reset
+vector is normalised to sum 1; a walker leaves vertex i along edge (i, j) with probability w_ij / strength(i), an
+undirected edge serving both directions, parallel edges adding up; a vertex without edges ('dangling') restarts
+according to the RESET distribution (PRPACK's personalised u = v), which is what `dangling=r` selects in networkx —
+networkx's default (dangling = personalization when given) is the same rule.
 """
 from __future__ import annotations
 

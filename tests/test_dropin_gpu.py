@@ -376,6 +376,57 @@ def test_pipelined_search_single_rank():
     plain.close()
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_id_block_table_translates_every_id_path(dtype):
+    """cmr_index_set_id_blocks (a row shard that took incremental appends: several runs of consecutive global ids).  Every
+    entry point that returns ids — single-launch search, general chain, wide batch, large k, threshold search, complete
+    ranking, pipelined — must return exactly the ids of the same index WITHOUT a table mapped through the table on the
+    host, and the entry points that take ids (re-score, row fetch) must accept the global ones."""
+    import torch
+    from comorag_amd import _lib as L
+    from comorag_amd.index import DenseIndex
+    n, d = 70_000, 128
+    X = orc.synthetic_corpus(n, d, seed=31); Q = orc.synthetic_queries(70, d, seed=32, planted=X)
+    ls = np.array([0, 40_000, 40_025, 65_000], np.int64)          # local starts
+    gs = np.array([1000, 900_000, 900_050, 2_000_000], np.int64)  # global starts (ascending, gaps between the runs)
+    def to_global(ids):
+        b = np.searchsorted(ls, ids, side="right") - 1
+        return np.where(ids >= 0, ids - ls[b] + gs[b], -1)
+    plain = DenseIndex(d, dtype, keep_f32=True); plain.append(X)
+    blk = DenseIndex(d, dtype, keep_f32=True); blk.append(X); blk.set_id_blocks(ls, gs)
+    small_p = DenseIndex(d, dtype); small_p.append(X[:900])
+    small_b = DenseIndex(d, dtype); small_b.append(X[:900]); small_b.set_id_blocks([0, 500], [7, 5000])
+    si, ss = small_p.search(Q[:3], 10)[:2]; bi, bs = small_b.search(Q[:3], 10)[:2]                  # single launch
+    assert np.array_equal(bi, np.where(si < 500, si + 7, si - 500 + 5000)) and np.array_equal(bs, ss)
+    for nq, k in ((1, 20), (9, 20), (70, 20), (4, 300)):                                            # general chain, wide batch (bf16: 70 > 64), large k
+        pi, ps = plain.search(Q[:nq], k)[:2]; gi, gsc = blk.search(Q[:nq], k)[:2]
+        assert np.array_equal(gi, to_global(pi)) and np.array_equal(gsc, ps), (nq, k)
+    pi, ps = plain.search_min_score(Q[:8], 16, 0.5); gi, gsc = blk.search_min_score(Q[:8], 16, 0.5)
+    assert np.array_equal(gi, to_global(pi)) and np.array_equal(gsc, ps)
+    pi, ps = plain.sorted_scores(Q[:2])[:2]; gi, gsc = blk.sorted_scores(Q[:2])[:2]
+    assert np.array_equal(gi, to_global(pi)) and np.array_equal(gsc, ps)
+    qt = torch.from_numpy(Q[:64]).cuda(); oi = torch.empty((64, 20), dtype=torch.int64, device="cuda"); osc = torch.empty((64, 20), device="cuda")
+    torch.cuda.synchronize()
+    blk.sync(blk.search_pipelined(qt, 20, oi, osc))
+    pi, ps = plain.search(Q[:64], 20)[:2]
+    assert np.array_equal(oi.cpu().numpy(), to_global(pi)) and np.array_equal(osc.cpu().numpy(), ps)
+    cand_l = plain.search(Q[:5], 100)[0]
+    ri, rs = plain.rescore(Q[:5], cand_l, 20); gi, gsc = blk.rescore(Q[:5], to_global(cand_l), 20)   # ids IN are global
+    assert np.array_equal(gi, to_global(ri)) and np.array_equal(gsc, rs)
+    rows_l = np.array([0, 39_999, 40_000, 40_024, 40_025, 69_999])
+    assert np.array_equal(blk.get_rows(to_global(rows_l)), plain.get_rows(rows_l))
+    assert not blk.get_rows(np.array([999, 41_000 + 1000, 900_025 + 10])).any()                     # ids in the gaps: no such row
+    # validation: overlapping runs, a table beyond the 32-bit row of the packed exchange, an id base that overflows it
+    with pytest.raises(L.CmrError):
+        blk.set_id_blocks([0, 10], [100, 105])
+    with pytest.raises(L.CmrError):
+        blk.set_id_blocks([0, 10], [100, 0xFFFFFFFF - 5])
+    with pytest.raises(L.CmrError):
+        plain.set_id_base(0xFFFFFFFF - 10)
+    for i in (plain, blk, small_p, small_b):
+        i.close()
+
+
 def test_rccl_exchange_path_one_rank(tmp_path):
     """The N>1 code path (ExternalStream on the pipeline's post stream → cmr_pack_candidates_dev → ONE RCCL
     all_gather_into_tensor → cmr_merge_keys_dev; and the library's own cmr_comm_allgather_merge) run mechanically
@@ -412,6 +463,7 @@ def test_rccl_exchange_path_one_rank(tmp_path):
         assert np.array_equal(b2["o_ids"].cpu().numpy(), wi + 500) and np.array_equal(b2["o_sc"].cpu().numpy(), ws)
         t = sh2.exchange_times_ms()
         assert len(t) == 6 and all(a >= 0 and m >= 0 for a, m in t)
+        assert sh2.comm_info() == {"world": 1, "rank": 0, "rccl_ranks_seen": 1}, sh2.comm_info()
         sh2.close()
         dist.destroy_process_group()
         print("EXCHANGE_OK")

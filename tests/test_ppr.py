@@ -39,6 +39,44 @@ def test_oracle_closed_forms():
     np.testing.assert_allclose(ppr_np.personalized_pagerank(40, src, dst, w, r, d), y, atol=1e-14)
 
 
+def _networkx_ppr(n, src, dst, w, reset, damping):
+    """networkx.pagerank (3.x, scipy power iteration) with the reset vector as personalization AND as dangling
+    distribution — the convention of igraph_personalized_pagerank / PRPACK that ComoRAG.py:1095-1102 calls: reset
+    normalised to sum 1, walker leaves i along (i, j) with probability w_ij / strength(i) (an undirected edge serves both
+    directions, parallel edges add up), a vertex without edges restarts from the reset distribution."""
+    import networkx as nx
+    G = nx.Graph()
+    G.add_nodes_from(range(n))
+    for u, v, x in zip(np.asarray(src).tolist(), np.asarray(dst).tolist(), np.asarray(w, np.float64).tolist()):
+        if G.has_edge(u, v):
+            G[u][v]["weight"] += x
+        else:
+            G.add_edge(u, v, weight=x)
+    r = np.asarray(reset, np.float64)
+    r = np.where(np.isnan(r) | (r < 0), 0.0, r)                    # ComoRAG.py:1090
+    pers = {i: float(r[i]) for i in range(n)}
+    pr = nx.pagerank(G, alpha=damping, personalization=pers, weight="weight", dangling=pers, tol=1e-15, max_iter=2000)
+    return np.array([pr[i] for i in range(n)])
+
+
+@pytest.mark.parametrize("n,m,isolated,seed", [(40, 150, (7,), 1), (50, 200, (3, 17), 50), (300, 900, (5, 6, 250), 4), (12, 10, (0, 1, 2, 3), 9)])
+def test_oracle_equals_networkx_pagerank(n, m, isolated, seed):
+    """Third-party pin of oracle/ppr_np.py (python-igraph / prpack are absent from the image): an independent published
+    implementation of the same personalised PageRank, on random weighted graphs with isolated vertices, seeds on isolated
+    vertices, negative and NaN reset entries, two damping values."""
+    src, dst, w = _random_graph(n, m, seed, isolated)
+    rng = np.random.default_rng(seed + 100)
+    reset = np.where(rng.uniform(0, 1, n) < 0.3, rng.uniform(0, 1, n), 0.0)
+    reset[isolated[0]] = 0.7                  # a seed on a vertex without edges keeps restarting from the reset distribution
+    reset[(isolated[0] + 1) % n] = -0.5
+    reset[(isolated[0] + 2) % n] = np.nan
+    for d in (0.5, 0.85):
+        got = ppr_np.personalized_pagerank(n, src, dst, w, reset, d)
+        want = _networkx_ppr(n, src, dst, w, reset, d)
+        np.testing.assert_allclose(got, want, atol=1e-12, rtol=0)
+        assert abs(got.sum() - 1.0) < 1e-12
+
+
 def test_oracle_passage_weights_and_run_ppr_shape():
     ids = np.array([2, 0, 1]); sc = np.array([1.0, 0.5, 0.0], np.float32)
     pw = ppr_np.passage_weights(ids, sc, [5, 6, 7], 8, 0.05)
@@ -111,6 +149,51 @@ def test_fused_dpr_seeded_ppr_equals_the_reference_pipeline(dtype):
         a_ids, a_sc = ppr_passage_ranking(idx, g, Q[qi], phrase, 0.05)
         order = np.argsort(want)[::-1]
         assert a_ids[:20].tolist() == order[:20].tolist()
+    idx.close(); g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_concurrent_ppr_calls_on_one_graph_do_not_share_scratch():
+    """ComoRAG.try_answer runs graph_search_with_fact_entities from a ThreadPoolExecutor (ComoRAG.py:437) and ctypes
+    releases the GIL: eight threads hammer ONE DeviceGraph with different queries / reset vectors (both entry points);
+    every result must equal the result of the same call made alone — bit for bit, the iteration order is fixed."""
+    import threading
+    from comorag_amd.index import DenseIndex
+    from comorag_amd.ppr import DeviceGraph, ppr_passage_scores
+    n_pass, n_ent, d = 4000, 1000, 64
+    X = orc.synthetic_corpus(n_pass, d, seed=21); Q = orc.synthetic_queries(8, d, seed=22, planted=X)
+    rng = np.random.default_rng(23)
+    nv = n_ent + n_pass
+    passage_vertex = (n_ent + rng.permutation(n_pass)).astype(np.int32)
+    src = np.concatenate([rng.integers(0, n_ent, 3 * n_pass), rng.integers(0, n_ent, 1500)]).astype(np.int32)
+    dst = np.concatenate([np.repeat(passage_vertex, 3), rng.integers(0, n_ent, 1500)]).astype(np.int32)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    idx = DenseIndex(d, "f32"); idx.append(X)
+    g = DeviceGraph(nv, src, dst, rng.uniform(0.5, 1.5, len(src))); g.set_passage_vertices(passage_vertex)
+    phrases, resets = [], []
+    for t in range(8):
+        ph = np.zeros(nv); ph[rng.integers(0, n_ent, 5)] = rng.uniform(0.2, 1.0, 5); phrases.append(ph)
+        rs = np.zeros(nv); rs[rng.integers(0, nv, 20)] = rng.uniform(0.1, 1.0, 20); resets.append(rs)
+    alone_a = [ppr_passage_scores(idx, g, Q[t], phrases[t], 0.05) for t in range(8)]
+    alone_b = [g.ppr(resets[t]) for t in range(8)]
+    bad = []
+
+    def worker(t):
+        for it in range(25):
+            a = ppr_passage_scores(idx, g, Q[t], phrases[t], 0.05)
+            b = g.ppr(resets[t])
+            if not (np.array_equal(a, alone_a[t]) and np.array_equal(b, alone_b[t])):
+                bad.append((t, it))
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert not bad, bad[:5]
+    # duplicate seed vertices add up (numpy's `w[v] += x` loop), in input order
+    sv = np.array([3, 9, 3, 3], np.int32); sw = np.array([0.25, 0.5, 0.125, 0.0625])
+    dense = np.zeros(nv); dense[3] = 0.25 + 0.125 + 0.0625; dense[9] = 0.5
+    np.testing.assert_array_equal(ppr_passage_scores(idx, g, Q[0], (sv, sw), 0.05), ppr_passage_scores(idx, g, Q[0], dense, 0.05))
     idx.close(); g.close()
 
 

@@ -60,6 +60,78 @@ def test_two_rank_gather_and_merge_equals_single_shard():
     assert res[0][2] == res[1][2]                          # every rank holds the same merged answer
 
 
+def _append_worker(rank, world, port, q_out):
+    """Incremental appends on a sharded index (BASELINE config 4 at N > 1): ids stay dense in append order,
+    every append goes to the shortest shard, searches between the appends equal one index over everything so far."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from comorag_amd.sharded import ShardedIndex, shard_bounds
+    from oracle import retrieval_np as orc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X = orc.synthetic_corpus(3001, 64, seed=7)               # bulk: shard 0 gets 1501 rows, shard 1 1500
+        Q = orc.synthetic_queries(6, 64, seed=8, planted=X)
+        lo, hi = shard_bounds(len(X), world, rank)
+
+        class Local:                                             # numpy stand-in for this rank's DenseIndex (append + len)
+            def __init__(self, x): self.x = x.copy()
+            def __len__(self): return len(self.x)
+            def append(self, rows): self.x = np.concatenate([self.x, rows])
+        loc = Local(X[lo:hi])
+        sh = ShardedIndex(64, "f32", rank=rank, world=world, base=lo, index=loc)
+        local_search = lambda q, k: orc.topk_rule(orc.exact_scores_f64(loc.x, q).astype(np.float32), k)
+        everything = X
+        ok, log = True, []
+        rng = np.random.default_rng(5)
+        for step, m in enumerate((25, 25, 3, 700, 1)):           # 700 rows in chunks of 256: spread over both shards
+            new = rng.standard_normal((m, 64)).astype(np.float32)
+            new /= np.linalg.norm(new, axis=1, keepdims=True)
+            if step == 1:
+                new[0] = X[10]                                   # duplicate of a bulk row: tie across blocks, lower global id first
+            got_ids = sh.append(new, block_rows=256)
+            ok &= got_ids.tolist() == list(range(len(everything), len(everything) + m))
+            everything = np.concatenate([everything, new])
+            qq = np.concatenate([Q, new[:2]])
+            ids, sc = sh.search(qq, 20, local_search=local_search)
+            want_i, want_s = orc.topk_rule(orc.exact_scores_f64(everything, qq).astype(np.float32), 20)
+            ok &= bool(np.array_equal(ids, want_i) and np.allclose(sc, want_s))
+            log.append((list(sh.sizes), len(sh.blocks)))
+        ok &= sum(sh.sizes) == len(everything) == sh.total and abs(sh.sizes[0] - sh.sizes[1]) <= 256
+        q_out.put((rank, ok, log))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_incremental_append_keeps_dense_global_ids():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_append_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok, _ in res), res
+    by_rank = dict((r, log) for r, _, log in res)
+    assert [s for s, _ in by_rank[0]] == [s for s, _ in by_rank[1]]        # the size table is identical on every rank
+    assert by_rank[0][0][0] == [1501, 1525]                                # the first append went to the shorter shard
+
+
+def test_route_is_deterministic_and_balances():
+    from comorag_amd.sharded import ShardedIndex
+
+    class Local:
+        def __len__(self): return 0
+    sh = ShardedIndex(8, "f32", rank=0, world=4, base=0, index=Local())
+    sh.sizes, sh.total = [10, 7, 7, 12], 36
+    assert sh._route(5, 8192) == [(1, 5)]
+    assert sh._route(20, 8) == [(1, 8), (2, 8), (0, 4)]
+
+
 def test_shard_bounds_cover_rows_exactly():
     from comorag_amd.sharded import shard_bounds
     for n in (0, 1, 7, 8, 10_000_000, 4001):

@@ -49,6 +49,33 @@ def _worker(rank, world, port, q_out):
             for i in range(len(Q)):
                 orc.assert_topk_equivalent(ids[i], ref_ids[i], exact[i], 4e-6)
             tie = sorted(int(x) for x in ids[0][:4])
+            # incremental appends between searches (BASELINE config 4 at N > 1): ids stay dense in append order, chunks go to
+            # the shortest shard, the device path (pipelined scan -> remap through the block table -> pack -> gloo all-gather
+            # staged through the host -> key merge) and the host path both equal ONE index that took the same appends
+            import torch
+            rng = np.random.default_rng(19)
+            for step, m in enumerate((25, 25, 5000, 1)):
+                new = rng.standard_normal((m, d)).astype(np.float32)
+                new /= np.linalg.norm(new, axis=1, keepdims=True)
+                if step == 0:
+                    new[3] = X[11]                                # a fifth copy of row 11, in an appended block
+                n_before = len(one)
+                got = sh.append(new, block_rows=2048)
+                one.append(new)
+                same &= got.tolist() == list(range(n_before, n_before + m))
+                qq = np.concatenate([Q, new[:3]])
+                ids, sc = sh.search(qq, k)
+                w_ids, w_sc = one.search(qq, k)[:2]
+                same &= bool(np.array_equal(ids, w_ids) and np.array_equal(sc, w_sc))
+                qt = torch.from_numpy(qq).cuda()
+                torch.cuda.synchronize()
+                b = sh.search_pipelined(qt, k, step & 1)
+                b["done"].synchronize()
+                same &= bool(np.array_equal(b["o_ids"].cpu().numpy(), w_ids) and np.array_equal(b["o_sc"].cpu().numpy(), w_sc))
+            same &= sum(sh.sizes) == len(one) and abs(sh.sizes[0] - sh.sizes[1]) <= 2048 and len(sh.blocks) >= 2
+            # ids coming IN are translated too: exact re-score of global candidates, row fetch by global id
+            mine = [g for g in (n + 3, n + 30, n + 5050) if sh.local.get_rows(np.array([g]))[0].any()]
+            same &= all(np.array_equal(sh.local.get_rows(np.array([g]))[0], one.get_rows(np.array([g]))[0]) for g in mine)
             one.close(); sh.close()
             q_out.put((rank, same, tie, ""))
         finally:

@@ -172,6 +172,20 @@ def test_sidecar_load_survives_a_crash_between_the_two_appends(tmp_path):
     c = EmbeddingStore(FakeEmbedder(8), d, 8, "chunk", persist="sidecar")
     assert c.hash_ids == want_ids + [compute_mdhash_id("three", prefix="chunk-")] and len(c.embeddings) == 3
     np.testing.assert_array_equal(c.get_embedding(c.hash_ids[2]), FakeEmbedder(8)._vec("three"))
+    # the very FIRST append crashed after the vectors, before any id line: orphan vectors, no id file.  The store comes up
+    # empty, and what is inserted next must be bound to ITS vectors on the following load (not to the orphans)
+    f0 = str(tmp_path / "first")
+    os.makedirs(f0)
+    with open(os.path.join(f0, "vdb_chunk.f32"), "wb") as f:
+        f.write(orphan.tobytes())
+    with open(os.path.join(f0, "vdb_chunk.meta.json"), "w") as f:
+        f.write('{"dim": 8, "dtype": "float32", "format": 2}')
+    g0 = EmbeddingStore(FakeEmbedder(8), f0, 8, "chunk", persist="sidecar")
+    assert g0.hash_ids == [] and not os.path.exists(g0._mat_file)
+    g0.insert_strings(["one", "two"])
+    g1 = EmbeddingStore(FakeEmbedder(8), f0, 8, "chunk", persist="sidecar")
+    assert g1.hash_ids == want_ids and os.path.getsize(g1._mat_file) == 2 * 8 * 4
+    np.testing.assert_array_equal(g1.get_embeddings(g1.get_all_ids()), want)
     # import path: a parquet file next to stale sidecar vectors (crashed first append, no id file): the parquet rows win
     p = str(tmp_path / "p")
     EmbeddingStore(FakeEmbedder(8), p, 8, "chunk").insert_strings(["one", "two"])
