@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """bench.py — brute-force top-k QPS of the HIP dense-retrieval engine on synthetic 768-d corpora.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU.  Launched either by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(WORLD_SIZE / RANK / LOCAL_RANK in the environment) or plainly as `python bench.py --gpus N`, in which case this script
+re-executes itself under torch.distributed.run on a free port (it fails with a clear message when the node shows fewer
+than N GPUs).  `--backend gloo --share-device` runs the whole N > 1 control flow with all ranks on cuda:0 and the
+candidate exchange staged through the host — the rehearsal a 1-GPU box allows (tests/test_bench_multirank_gpu.py).
 
 Step      = one batch of B queries against the whole (row-sharded) corpus: query packing, sampling passes, the fused
             MFMA scan + top-k kernel, candidate merge; for N>1 also the ONE RCCL all-gather of the packed per-shard
@@ -20,6 +25,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,7 +53,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "cabi"], help="N>1: torch.distributed collective or the library's own RCCL call")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "cabi"],
+                    help="N>1: binding of the batch-64 exchange — torch.distributed collective or the library's own RCCL call; batch 256 runs through the OTHER one")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="N>1: nccl (= RCCL over xGMI) or gloo (host collective; with --share-device)")
+    ap.add_argument("--share-device", action="store_true", help="N>1: every rank on cuda:0 (1-GPU rehearsal of the multi-rank flow; needs --backend gloo)")
+    ap.add_argument("--query-batches", type=int, default=4, help="distinct query batches rotated through the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -82,9 +93,24 @@ def build_shard(torch, args, rows, rank, world, device, host=None, timing=False)
     return sh
 
 
-def run_steps(torch, dist, sh, q, k, steps, warmup, world, device, every=PROFILE_EVERY):
+def make_queries(torch, n_batches, batch, dim, device, seed):
+    """n_batches distinct batches of unit queries: the timed steps rotate through them, so the data-dependent part of a
+    step (sampling thresholds, slow-path frequency) is not one sample."""
+    out = []
+    for j in range(n_batches):
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + 7919 * j)
+        q = torch.randn((batch, dim), generator=g, device=device, dtype=torch.float32)
+        out.append((q / q.norm(dim=1, keepdim=True)).contiguous())
+    torch.cuda.synchronize(device)
+    return out
+
+
+def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFILE_EVERY, ctl="cuda"):
+    """qs: list of query batches, step i takes qs[i % len(qs)].  Returns (seconds, profile, last batch's buffers, index of
+    the query batch of the last step)."""
     for i in range(warmup):
-        sh.search_pipelined(q, k, i & 1)["done"].synchronize()
+        sh.search_pipelined(qs[i % len(qs)], k, i & 1)["done"].synchronize()
     torch.cuda.synchronize(device)
     sh.times = []
     sh.local.profile(every)       # HIP events around every `every`-th main scan of the timed region
@@ -94,7 +120,7 @@ def run_steps(torch, dist, sh, q, k, steps, warmup, world, device, every=PROFILE
     t0 = time.perf_counter()
     last = None
     for i in range(steps):
-        last = sh.search_pipelined(q, k, i & 1)
+        last = sh.search_pipelined(qs[i % len(qs)], k, i & 1)
     last["done"].synchronize()
     torch.cuda.synchronize(device)
     if world > 1:
@@ -103,13 +129,13 @@ def run_steps(torch, dist, sh, q, k, steps, warmup, world, device, every=PROFILE
     sh.local.profile(False)
     prof = sh.local.profile_collect()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if ctl == "cuda" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ex = sh.exchange_times_ms() if sh.timing else []
     prof["exchange_ms"] = float(np.mean([a for a, _ in ex])) if ex else 0.0
     prof["merge_ms"] = float(np.mean([m for _, m in ex])) if ex else 0.0
-    return dt, prof, last
+    return dt, prof, last, (steps - 1) % len(qs)
 
 
 def verify_last_batch(sh, last, qh, k):
@@ -256,27 +282,6 @@ def single_query_latency(torch, args, device, sizes=(6, 1000, 10_000, 100_000)):
             "all_scores_rows": all_scores, "all_scores_note": "cmr_index_scores, one query: what dense_passage_retrieval / get_fact_scores call (median of 30)"}
 
 
-def encode_rate(torch, device, kind="base", n_chunks=256, dtype="auto"):
-    """Corpus-embed chunks/s: tokenise + encoder forward (PyTorch-ROCm, random-init BERT of BGE shape)
-    + HIP masked mean-pool/L2-norm, batch 32, ~480-token chunks truncated to 512 positions."""
-    from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
-    from comorag_amd.utils.config_utils import BaseConfig
-    from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
-    tok, words = synthetic_wordpiece_tokenizer()
-    cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_batch_size=32, embedding_model_dtype=dtype,
-                     device=device.index or 0)
-    em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert(kind, vocab_size=len(tok)), tokenizer=tok)
-    chunks = synthetic_chunks(words, n_chunks)
-    em.batch_encode(chunks[:64])
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    out = em.batch_encode(chunks)
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    return {"value": n_chunks / dt, "unit": "chunks/s", "model": f"BERT-{kind} shape, random init, {dtype}", "batch": 32,
-            "chunks": n_chunks, "embedding_dim": int(out.shape[1])}
-
-
 def summarise(batch, steps, dt, prof, rows_gpu, dim):
     ms = prof["total_ms"] / max(prof["launches"], 1)
     return {"value": batch * steps / dt, "unit": "queries/s", "batch": batch, "ms_per_step": dt / steps * 1e3, "kernel_ms": ms,
@@ -286,30 +291,62 @@ def summarise(batch, steps, dt, prof, rows_gpu, dim):
             "exchange_ms": prof["exchange_ms"], "merge_ms": prof["merge_ms"]}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if args.share_device:
+        if have < 1:
+            raise SystemExit("bench.py --share-device needs one visible MI355X; comorag_amd has no CPU fallback")
+        if args.backend != "gloo":
+            raise SystemExit("bench.py --share-device: ranks sharing one GPU cannot form an RCCL group; add --backend gloo")
+    elif have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s) (torch.cuda.device_count()); one rank per GPU is required "
+                         f"(use --backend gloo --share-device to rehearse the multi-rank flow on one GPU)")
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; comorag_amd has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    if args.share_device and args.backend != "gloo":
+        raise SystemExit("--share-device needs --backend gloo")
+    if world > 1 and not args.share_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world}: only {torch.cuda.device_count()} GPU(s) visible; one rank per GPU is required")
+    device = torch.device("cuda", 0 if args.share_device else local_rank)
     torch.cuda.set_device(device)
+    ctl = "cuda" if args.backend == "nccl" else "cpu"          # where the control-plane tensors of this backend live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     from comorag_amd import _lib as L
-    info = L.device_info(local_rank)
+    info = L.device_info(device.index or 0)
+    # exchange bindings: batch 64 through --exchange, batch 256 through the other one, so that both get hardware time on a
+    # multi-GPU node; on a gloo group only the torch binding exists (RCCL needs one device per rank)
+    ex64 = args.exchange if args.backend == "nccl" else "torch"
+    ex256 = ({"torch": "cabi", "cabi": "torch"}[ex64]) if args.backend == "nccl" else "torch"
+    args.exchange = ex64
 
-    g = torch.Generator(device=device)
-    g.manual_seed(4321)
-    q = torch.randn((args.batch, args.dim), generator=g, device=device, dtype=torch.float32)
-    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
-    qh = q.cpu().numpy()
+    qs = make_queries(torch, max(1, args.query_batches), args.batch, args.dim, device, 4321)
+    qh = qs[0].cpu().numpy()
 
     # fp32 host copy of the corpus for the CPU legs (rank 0, N=1 only): needs rows*dim*4 bytes + slack
     host = None
@@ -323,8 +360,10 @@ def main():
         except Exception:
             host = None
     sh = build_shard(torch, args, args.rows, rank, world, device, host=host, timing=world > 1)
-    dt, prof, last = run_steps(torch, dist, sh, q, args.k, args.steps, args.warmup, world, device)
-    gpu_ids, gpu_sc, same = verify_last_batch(sh, last, qh, args.k)
+    dt, prof, last, qi = run_steps(torch, dist, sh, qs, args.k, args.steps, args.warmup, world, device, ctl=ctl)
+    gpu_ids, gpu_sc, same = verify_last_batch(sh, last, qs[qi].cpu().numpy(), args.k)
+    if qi != 0:                 # recall is computed for batch 0 (the CPU ranking of one batch is the expensive part)
+        gpu_ids = sh.search(qh, args.k)[0]
     head = summarise(args.batch, args.steps, dt, prof, len(sh), args.dim)
     out = {
         "metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -332,9 +371,10 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} "
                                f"(north_star target config; corpus fixed, row-sharded over {world} GPU(s))",
-                   "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k,
+                   "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "query_batches_rotated": len(qs),
                    "sharding": f"rows/{world}", "device": info["name"], "n_cu": info["n_cu"],
-                   "exchange": "none (1 shard)" if world == 1 else f"one packed-u64 all-gather per batch ({args.exchange} binding) + device key merge"},
+                   "exchange": "none (1 shard)" if world == 1 else f"one packed-u64 all-gather per batch ({ex64} binding over {args.backend}"
+                                                                   f"{', ranks share cuda:0, keys staged through the host' if args.share_device else ''}) + device key merge"},
         "roofline": {"bound": "hbm", "achieved": head["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac_of_8TBps"],
                      "frac_of_achievable_6290": head["hbm_GBps"] / HBM_ACHIEVABLE_GBS, "traffic": None,
                      "kernel": "scan_kernel (fused MFMA scan + top-k)", "kernel_ms": head["kernel_ms"],
@@ -347,33 +387,51 @@ def main():
 
     # BASELINE config 3 as written: the same (sharded) corpus, batch 256 — one corpus pass of the wide kernel per batch
     c3 = None
+    same_w = True
+    q256 = None
     if not args.no_extra and args.batch != 256 and args.dim in (768, 1024):
-        g2 = torch.Generator(device=device); g2.manual_seed(8765)
-        q256 = torch.randn((256, args.dim), generator=g2, device=device, dtype=torch.float32)
-        q256 = (q256 / q256.norm(dim=1, keepdim=True)).contiguous()
-        torch.cuda.synchronize(device)
+        q256 = make_queries(torch, max(1, min(args.query_batches, 3)), 256, args.dim, device, 8765)
         steps_w = max(10, args.steps // 2)
-        dtw, profw, lastw = run_steps(torch, dist, sh, q256, args.k, steps_w, 3, world, device)
-        _, _, same_w = verify_last_batch(sh, lastw, q256.cpu().numpy(), args.k)
+        shw = sh.view(ex256, timing=world > 1) if world > 1 else sh
+        dtw, profw, lastw, qiw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl)
+        _, _, same_w = verify_last_batch(shw, lastw, q256[qiw].cpu().numpy(), args.k)
         c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim)
-        c3["kernel"] = "scan_wide_kernel (256 queries resident in registers: 4 waves x 2 tiles, LDS-DMA corpus ring)"
+        c3["kernel"] = "scan_wide_kernel (256 queries resident in registers, LDS-DMA corpus ring)"
         c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
         c3["last_pipelined_batch_equals_synchronous_search"] = same_w
-        c3["note"] = ("at the HBM/MFMA ridge and power-limited: a pure MFMA loop on this operand distribution sustains 1.45-1.83 PFLOP/s "
-                      "chip-wide (tools/probe/mfma_probe.hip), not 2.5")
+        c3["exchange_binding"] = ex256 if world > 1 else None
+        if world > 1 and args.backend == "nccl":
+            try:
+                c3["rccl_ranks_seen"] = (shw if ex256 == "cabi" else sh).comm_info()["rccl_ranks_seen"]
+            except Exception as e:
+                c3["rccl_ranks_seen"] = repr(e)[:200]
     if world > 1:
-        mine = {"rank": rank, "rows": len(sh), "batch64": {k_: head[k_] for k_ in ("kernel_ms", "exchange_ms", "merge_ms", "ms_per_step")},
+        out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] = same_w
+        out["exchange_bindings"] = {"batch64": ex64, "batch256": ex256 if c3 else None, "backend": args.backend, "share_device": bool(args.share_device),
+                                    "torch_world_size": dist.get_world_size()}
+        if args.backend == "nccl":
+            try:        # ranks RCCL itself reports for the library's own communicator (ncclCommCount)
+                cv = sh if ex64 == "cabi" else (shw if c3 else sh.view("cabi"))
+                out["exchange_bindings"]["rccl_ranks_seen"] = cv.comm_info()["rccl_ranks_seen"]
+            except Exception as e:
+                out["exchange_bindings"]["rccl_ranks_seen"] = repr(e)[:200]
+        mine = {"rank": rank, "rows": len(sh), "device": str(device), "batch64": {k_: head[k_] for k_ in ("kernel_ms", "exchange_ms", "merge_ms", "ms_per_step")},
                 "batch256": {k_: c3[k_] for k_ in ("kernel_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
         box = [None] * world
         dist.all_gather_object(box, mine)
         out["per_rank"] = box
-    prof_file = os.path.join(ROOT, "profiles", "r2_pmc_hbm_traffic.json")
-    if os.path.exists(prof_file):
-        pj = json.load(open(prof_file))
-        w = pj.get("workload", {})
-        if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (len(sh), args.dim, args.dtype, args.batch, args.k):
-            out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r2_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 correction)"
+    for prof_file in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
+        prof_file = os.path.join(ROOT, "profiles", prof_file)
+        if os.path.exists(prof_file):
+            pj = json.load(open(prof_file))
+            w = pj.get("workload", {})
+            if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (len(sh), args.dim, args.dtype, args.batch, args.k):
+                out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(prof_file)}: a committed measurement of this command (rocprofv3 --pmc FETCH_SIZE / "
+                                                     "WRITE_SIZE passes, FETCH x2 gfx950 correction), not of this run")
+                break
+    if world > 1 and c3 and shw is not sh:
+        shw.close()
     sh.close()
     del sh
     out["cpu_baseline"] = None
@@ -381,14 +439,17 @@ def main():
     if c3 is not None:
         extra["config3_batch256"] = c3
     if rank == 0 and world == 1 and not args.no_extra:
+        q = qs
         from comorag_amd.sharded import ShardedIndex
         # BASELINE config 2 (1 M rows) and one 8-GPU shard of config 3 (1.25 M rows) on this GPU
         for name, rows2, batches in (("config2", min(args.rows, 1_000_000), (args.batch,)), ("config3_one_of_8_shards", min(args.rows, 1_250_000), (args.batch, 256))):
             sh2 = build_shard(torch, args, rows2, 0, 1, device)
             for b2 in batches:
+                if b2 != args.batch and q256 is None:
+                    continue
                 qq = q if b2 == args.batch else q256
                 steps2 = max(args.steps, 100)
-                dt2, prof2, _ = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device)
+                dt2, prof2, _, _ = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device)
                 extra[f"{name}_{rows2}_rows_batch{b2}"] = summarise(b2, steps2, dt2, prof2, rows2, args.dim)
             if name == "config2":
                 try:
@@ -441,11 +502,23 @@ def main():
                 full, ids_for_recall = True, gpu_ids
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, host, qh, ids_for_recall, full)
         del host
-        try:
-            extra["corpus_embed"] = encode_rate(torch, device, "base", 256, "auto")
-            extra["corpus_embed_bf16"] = encode_rate(torch, device, "base", 256, "bf16")
-        except Exception as e:  # the headline line must still print
-            extra["corpus_embed"] = {"error": repr(e)[:300]}
+        # BASELINE configs 4 / 5, SURVEY 8 f1 / f4, and the encode leg of the metric with its breakdown (tools/bench_extras.py)
+        from tools import bench_extras as bx
+        rows = (("config4_probe_loop", lambda: bx.config4_probe_loop(torch, device, dim=args.dim, dtype=args.dtype, rows0=min(2_000_000, max(args.rows, 200_000)), k=args.k)),
+                ("corpus_embed", lambda: bx.encode_breakdown(torch, device, "base", "auto", 128)[0]),
+                ("corpus_embed_bf16", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 256)[0]),
+                ("corpus_embed_bf16_tokenizer_processes", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 256, tok_processes=4)[0]),
+                ("config5_bge_large_fp16_encode_search_rescore", lambda: bx.config5_encode_search_rescore(torch, device)),
+                ("f1_synonymy_selfjoin", lambda: bx.f1_selfjoin(torch, device, dim=args.dim)),
+                ("f4_dpr_seeded_ppr", lambda: bx.f4_ppr(torch, device)))
+        for name, fn in rows:
+            try:
+                t0 = time.perf_counter()
+                extra[name] = fn()
+                extra[name]["bench_seconds"] = time.perf_counter() - t0
+            except Exception as e:  # the headline line must still print
+                extra[name] = {"error": repr(e)[:400]}
+            torch.cuda.empty_cache()
     if extra:
         out["extra"] = extra
     if rank == 0:
@@ -453,7 +526,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if not same:
+    if not (same and same_w):
         raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
 
 

@@ -112,6 +112,15 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self._bucket = bool(cfg_get(self.global_config, "embedding_length_bucketing", True))
         self._tok_workers = max(1, min(int(cfg_get(self.global_config, "embedding_tokenizer_threads", 2)), os.cpu_count() or 1))
         self._tok_pool = ThreadPoolExecutor(max_workers=self._tok_workers, thread_name_prefix="cmr-tok")
+        # optional tokenizer PROCESSES (the Rust tokenizer holds the GIL while it encodes: threads share the core that also
+        # launches the encoder's kernels).  Spawned, tokenizers-only workers (_tokworker.py); used by the length-bucketed path.
+        self._tok_procs = None
+        n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", 0) or 0)
+        if n_procs > 0 and hasattr(tokenizer, "backend_tokenizer"):
+            import multiprocessing as mp
+            from . import _tokworker
+            self._tok_procs = mp.get_context("spawn").Pool(min(n_procs, os.cpu_count() or 1), initializer=_tokworker.init,
+                                                           initargs=(tokenizer.backend_tokenizer.to_str(),))
         self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
         if self._cached:
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
@@ -137,7 +146,8 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
     def _forward_pool(self, inputs, normalize: bool):
         import torch
         with torch.no_grad():
-            inputs = {k: v.to(self.device, non_blocking=True) for k, v in inputs.items()}
+            # pinned staging + non-blocking copies: the id tensors of mini-batch i+1 cross the link while batch i computes
+            inputs = {k: (v.pin_memory() if not v.is_cuda else v).to(self.device, non_blocking=True) for k, v in inputs.items()}
             hidden = self.embedding_model(**inputs).last_hidden_state
             return pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize)
 
@@ -157,6 +167,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         import torch
         if isinstance(texts, str):
             texts = [texts]
+        return_device = bool(kwargs.pop("_return_device", False))
         params = deepcopy(self.embedding_config.encode_params)
         if kwargs:
             params.update(kwargs)
@@ -188,8 +199,13 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                 # 1. token ids of everything (worker threads, reference chunks), 2. stable sort by token count,
                 # 3. mini-batches of `batch_size` neighbours, each padded to its own longest, 4. scatter back
                 ml = min(int(max_length), self.max_positions)
-                rag = lambda c: tokenize_ragged(self.tokenizer, [instr + t for t in c] if instr else list(c), ml)
-                id_lists = [x for part in self._tok_pool.map(rag, chunks) for x in part]
+                if self._tok_procs is not None:
+                    from . import _tokworker
+                    jobs = [self._tok_procs.apply_async(_tokworker.ragged, ([instr + t for t in c] if instr else list(c), ml)) for c in chunks]
+                    id_lists = [x for j in jobs for x in j.get()]
+                else:
+                    rag = lambda c: tokenize_ragged(self.tokenizer, [instr + t for t in c] if instr else list(c), ml)
+                    id_lists = [x for part in self._tok_pool.map(rag, chunks) for x in part]
                 lens = np.array([len(x) for x in id_lists])
                 order = np.argsort(lens, kind="stable")
                 # a mini-batch holds as many rows as fit the token budget of a full-length one (batch_size x ml padded
@@ -223,11 +239,32 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                         futs.append(self._tok_pool.submit(prep, chunks[i + ahead]))
                     parts.append(self._forward_pool(inputs, normalize))
                 results = torch.cat(parts, dim=0)
+        if return_device and isinstance(results, torch.Tensor) and not (self.embedding_config.norm and not kwargs.get("normalize", True)):
+            return results.float().contiguous()
         if isinstance(results, torch.Tensor):
             results = results.float().cpu().numpy()
         if self.embedding_config.norm and not kwargs.get("normalize", True):
             results = (results.T / np.linalg.norm(results, axis=1)).T
         return results
+
+    def batch_encode_dev(self, texts: Union[str, List[str]], **kwargs):
+        """`batch_encode` that leaves the rows where the encoder put them: a torch fp32 CUDA tensor [n, D].
+        EmbeddingStore.insert_strings appends it to the HBM index as it is (cmr_index_append_dev) instead of copying the
+        rows to the host and uploading them again; the host copy the store keeps is made from the same tensor."""
+        return self.batch_encode(texts, _return_device=True, **kwargs)
+
+    def close(self) -> None:
+        if getattr(self, "_tok_procs", None) is not None:
+            self._tok_procs.terminate()
+            self._tok_procs = None
+        if getattr(self, "_tok_pool", None) is not None:
+            self._tok_pool.shutdown(wait=False)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def encode_queries(self, queries, **kwargs) -> np.ndarray:
         kwargs["is_query"] = True

@@ -237,7 +237,7 @@ class EmbeddingStore:
         pq.write_table(table, tmp)
         os.replace(tmp, self.filename)
 
-    def _upsert(self, hash_ids, texts, embeddings):
+    def _upsert(self, hash_ids, texts, embeddings, dev_rows=None):
         emb = np.asarray(embeddings)
         if emb.ndim == 1:
             emb = emb[None, :]
@@ -250,7 +250,10 @@ class EmbeddingStore:
         self.hash_ids.extend(hash_ids)
         self.texts.extend(texts)
         if self._index is not None:
-            self._index.append(new_rows)
+            if dev_rows is not None and hasattr(self._index, "append_dev"):
+                self._index.append_dev(dev_rows)
+            else:
+                self._index.append(new_rows)
         logger.info("Saving new records.")
         if self.persist == "sidecar":
             self._append_sidecar(hash_ids, texts, new_rows)
@@ -290,7 +293,17 @@ class EmbeddingStore:
             logger.info(f"Inserting {len(ids)} new records, {n_seen - len(ids)} records already exist.")
             if not ids:
                 return {}
-            self._upsert(ids, new_texts, self.embedding_model.batch_encode(new_texts))
+            enc_dev = getattr(self.embedding_model, "batch_encode_dev", None)
+            if self._index is not None and enc_dev is not None:
+                # the HBM mirror exists: the encoder's device tensor goes into it as it is (cmr_index_append_dev); the host
+                # matrix gets its copy from the same tensor — no D2H -> numpy -> H2D round trip of the new rows
+                dev_rows = enc_dev(new_texts)
+                if hasattr(dev_rows, "is_cuda") and dev_rows.is_cuda:
+                    self._upsert(ids, new_texts, dev_rows.cpu().numpy(), dev_rows=dev_rows)
+                else:
+                    self._upsert(ids, new_texts, np.asarray(dev_rows))
+            else:
+                self._upsert(ids, new_texts, self.embedding_model.batch_encode(new_texts))
 
     def get_row(self, hash_id):
         return self.hash_id_to_row[hash_id]

@@ -233,3 +233,56 @@ def test_fp32_index_one_million_rows_vs_host_oracle():
         np.testing.assert_allclose(norm, orc.min_max_normalize(s32[i])[ids[i]], atol=2e-6)
     assert n_diff <= 2, n_diff            # identical ids is the rule; a swap needs two scores within fp32 rounding of each other
     idx.close()
+
+
+@pytest.mark.timeout(600)
+def test_fp32_index_ten_million_rows_vs_host_oracle():
+    """The same fp32 claim at the HEADLINE size: 10 M x 768 fp32 rows (30.7 GB of HBM), k = 20, B = 8, against the host
+    fp32 GEMM the reference runs (np.dot -> OpenBLAS) taken in 250 K-row blocks with a running top-k; ids identical up to
+    ties inside the fp32 accumulation bound (arbitrated in fp64 on the rows in question).  Rows are generated on the device
+    (seeded, per block) and copied back block by block, so the host never holds more than one block."""
+    import torch
+    from comorag_amd.index import DenseIndex
+    n, d, b, k, blk = 10_000_000, 768, 8, 20, 250_000
+    dev = torch.device("cuda", 0)
+    idx = DenseIndex(d, "f32", capacity_hint=n)
+    rng = np.random.default_rng(99)
+    Q = rng.standard_normal((b, d)).astype(np.float32); Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    best_s = np.full((b, 0), -np.inf, np.float32); best_i = np.zeros((b, 0), np.int64)
+    keep_rows = {}
+    gmin, gmax = np.full(b, np.inf, np.float32), np.full(b, -np.inf, np.float32)
+    for bi in range(n // blk):
+        g = torch.Generator(device=dev); g.manual_seed(777_000 + bi)
+        x = torch.randn((blk, d), generator=g, device=dev, dtype=torch.float32)
+        x = (x / x.norm(dim=1, keepdim=True)).contiguous()
+        if bi % 5 == 0:                                          # a planted near-neighbour of query (bi / 5) % b in this block
+            qi = (bi // 5) % b
+            x[1234 + bi] = torch.from_numpy(Q[qi]).to(dev) + 0.05 * x[1234 + bi]
+            x[1234 + bi] /= x[1234 + bi].norm()
+        idx.append_dev(x)
+        xh = x.cpu().numpy()
+        s = Q @ xh.T                                             # the reference's arithmetic (ComoRAG.py:958-962) on this block
+        gmin, gmax = np.minimum(gmin, s.min(1)), np.maximum(gmax, s.max(1))
+        part = np.argpartition(-s, 2 * k, axis=1)[:, :2 * k]
+        cs = np.concatenate([best_s, np.take_along_axis(s, part, 1)], 1); ci = np.concatenate([best_i, part + bi * blk], 1)
+        order = np.lexsort((ci, -cs), axis=1)[:, :2 * k]         # score descending, id ascending: the exported rule
+        best_s, best_i = np.take_along_axis(cs, order, 1), np.take_along_axis(ci, order, 1)
+        for r in np.unique(best_i):
+            if r // blk == bi:
+                keep_rows[int(r)] = xh[r - bi * blk].copy()
+    ids, sc, mn, mx = idx.search(Q, k)
+    n_diff = 0
+    for i in range(b):
+        ref = best_i[i, :k]
+        if not np.array_equal(ids[i], ref):
+            n_diff += 1
+            cols = np.union1d(ids[i], best_i[i])
+            assert all(int(c) in keep_rows for c in ids[i]), "the index returned a row the host ranking never had among its 40 best"
+            ex = {int(c): float(keep_rows[int(c)].astype(np.float64) @ Q[i].astype(np.float64)) for c in cols if int(c) in keep_rows}
+            exv = np.full(n, -np.inf); exv[list(ex)] = list(ex.values())
+            orc.assert_topk_equivalent(ids[i], ref, exv, 4e-6)
+        np.testing.assert_allclose(sc[i], best_s[i, :k], atol=2e-6)
+    assert n_diff <= 1, n_diff
+    np.testing.assert_allclose(mn, gmin, atol=2e-6); np.testing.assert_allclose(mx, gmax, atol=2e-6)
+    assert np.all(sc[:, 0] > 0.9)                                # every query has planted neighbours
+    idx.close()

@@ -233,6 +233,37 @@ def test_encoder_end_to_end_vs_oracle():
     np.testing.assert_allclose(em2.batch_encode(texts), got, atol=2e-5)
 
 
+def test_store_insert_appends_the_encoder_device_tensor(tmp_path):
+    """EmbeddingStore.insert_strings with an HBM mirror in place: the encoder's device tensor is appended as it is
+    (batch_encode_dev -> cmr_index_append_dev), the host matrix gets its copy from the same tensor — index rows, host rows
+    and a plain batch_encode of the same texts agree bit for bit; ids stay in insertion order."""
+    import copy
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.embedding_store import EmbeddingStore
+    from comorag_amd.utils.config_utils import BaseConfig
+    from oracle import encode_torch as enc
+    model, tok = enc.tiny_bert(hidden=128, layers=2, heads=4, inter=256, max_pos=64)
+    cfg = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=4)
+    em = _get_embedding_model_class(cfg.embedding_model_name)(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+    store = EmbeddingStore(em, str(tmp_path / "s"), 4, "chunk")
+    first = [f"the bird in the tree number {i}" for i in range(6)]
+    store.insert_strings(first)
+    idx = store.device_index("f32")
+    calls = []
+    orig = idx.append_dev
+    idx.append_dev = lambda t, *a, **k: (calls.append(tuple(t.shape)), orig(t, *a, **k))[1]
+    more = [f"the golden slipper number {i} " + "and the prince " * (i % 4) for i in range(9)]
+    store.insert_strings(more + first[:2])                       # two known texts are skipped
+    assert calls == [(9, 128)] and len(idx) == 15 and len(store.hash_ids) == 15
+    host = np.array(store.get_embeddings(store.get_all_ids()))
+    np.testing.assert_array_equal(idx.get_rows(np.arange(15)), host)
+    np.testing.assert_array_equal(host[6:], em.batch_encode(more))
+    t = em.batch_encode_dev(more)
+    assert t.is_cuda and tuple(t.shape) == (9, 128)
+    np.testing.assert_array_equal(t.cpu().numpy(), host[6:])
+    em.close()
+
+
 def test_hooks_on_a_comorag_shaped_object(golden_dir):
     """install() rebinds the numeric call sites on an object with ComoRAG's attribute names."""
     from comorag_amd import hooks

@@ -235,3 +235,21 @@ def test_length_bucketing_builds_the_tokenizers_own_tensors():
             assert set(got.keys()) == set(ref.keys())
             for key in ref:
                 assert torch.equal(got[key], ref[key]), (key, max_length)
+
+
+def test_tokenizer_worker_process_returns_what_the_in_process_tokenizer_returns():
+    """embedding_tokenizer_processes > 0: the spawned, tokenizers-only worker (comorag_amd/embedding_model/_tokworker.py)
+    must hand back exactly the id lists `tokenize_ragged` builds in-process — same truncation, same special tokens."""
+    import multiprocessing as mp
+    from comorag_amd.embedding_model import _tokworker
+    from comorag_amd.embedding_model.bge import tokenize_ragged
+    from tools.synthetic import synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer()
+    texts = synthetic_chunks(words, 6, tokens_per_chunk=560) + ["", "a", "   ", "short one"]
+    want = tokenize_ragged(tok, texts, 512)
+    assert max(len(x) for x in want) == 512 and min(len(x) for x in want) == 2
+    _tokworker.init(tok.backend_tokenizer.to_str())
+    assert _tokworker.ragged(texts, 512) == want
+    assert _tokworker.ragged(texts[:3], 64) == tokenize_ragged(tok, texts[:3], 64)
+    with mp.get_context("spawn").Pool(1, initializer=_tokworker.init, initargs=(tok.backend_tokenizer.to_str(),)) as pool:
+        assert pool.apply(_tokworker.ragged, (texts, 512)) == want
