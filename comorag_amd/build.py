@@ -115,7 +115,7 @@ def audit_ring(asm_text: str) -> dict:
     return result
 
 
-_WIDE_RE = re.compile(r"^_Z16scan_wide_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi0EEv5ScanP:")   # ABL = 0 only
+_WIDE_RE = re.compile(r"^_Z16scan_wide_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi0ELi(\d+)EEv5ScanP:")   # ABL = 0 only
 
 
 def audit_wide(asm_text: str) -> dict:
@@ -125,7 +125,7 @@ def audit_wide(asm_text: str) -> dict:
     than the epilogue instances account for (anything more means fragments are being shuttled between the register
     files in front of the MFMAs), and no compiler VALU write of an MFMA A/B operand register
     in the three instructions before an asm MFMA (VALU write -> MFMA read needs wait states hipcc does not insert).
-    Returns {(dt,ks,nt,cap): problem string or ''}."""
+    Returns {(dt,ks,nt,cap,waves): problem string or ''}."""
     result = {}
     lines = asm_text.split("\n")
     i = 0
@@ -134,7 +134,7 @@ def audit_wide(asm_text: str) -> dict:
         if not m:
             i += 1
             continue
-        dt, ks, nt, cap, nst, klds = (int(x) for x in m.groups())
+        dt, ks, nt, cap, nst, klds, nw = (int(x) for x in m.groups())
         j = i + 1
         body = []
         while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
@@ -170,7 +170,7 @@ def audit_wide(asm_text: str) -> dict:
                     problems.append(f"VALU write of an MFMA operand right before it: '{prev}' -> '{c}'")
         if n_mfma < ks * nt:
             problems.append(f"only {n_mfma} MFMAs found")
-        result[(dt, ks, nt, cap)] = "; ".join(problems)
+        result[(dt, ks, nt, cap, nw)] = "; ".join(problems)
     return result
 
 

@@ -145,18 +145,21 @@ struct cmr_index {
     unsigned prof_seq = 0;
     std::vector<ProfEvent> prof_events;
     double prof_bytes = 0.0;
-    // knobs (env)
-    int force_ring = 0;      // CMR_SCAN_RING=8|16
-    int force_asm = -1;      // CMR_SCAN_ASM_RING=0|1
-    int force_grid = 0;      // CMR_SCAN_GRID
-    int no_sample = 0;       // CMR_SCAN_NO_SAMPLE=1 disables the sampling pass
-    int no_wide = 0;         // CMR_SCAN_NO_WIDE=1 disables the wide-batch (register-resident query) kernel
-    int no_tiny = 0;         // CMR_SCAN_NO_TINY=1 disables the single-launch paths (search and all-scores) altogether
-    int single_level = 1;    // CMR_SAMPLE_SINGLE=0: small batches on mid-size corpora sample in two levels like everything else
-    int tiny_multi = 1;      // CMR_TINY_MULTI=0: the single-launch path always runs as one workgroup (<= 1024 rows only)
-    int small_max_panels = 6144;   // CMR_SMALL_MAX_PANELS: largest corpus (in 32-row panels) the single-launch path takes
-    int no_small = 0;        // CMR_SCAN_NO_SMALL=1: corpora of 1025 rows .. 64 K rows take the general path also for few queries
-    int zero_copy = 1;       // CMR_ZERO_COPY=0: the synchronous host API copies queries / results instead of mapping them
+    // route selectors (cmr_index_set_option; results never depend on them)
+    int force_ring = 0;      // scan_ring = 8 | 16
+    int force_asm = -1;      // scan_asm_ring = 0 | 1
+    int force_grid = 0;      // scan_grid
+    int no_sample = 0;       // scan_no_sample = 1 disables the sampling pass
+    int no_wide = 0;         // scan_no_wide = 1 disables the wide-batch (register-resident query) kernel
+    int no_tiny = 0;         // scan_no_tiny = 1 disables the single-launch paths (search and all-scores) altogether
+    int single_level = 1;    // sample_single = 0: small batches on mid-size corpora sample in two levels like everything else
+    int tiny_multi = 1;      // tiny_multi = 0: the single-launch path always runs as one workgroup (<= 1024 rows only)
+    int small_max_panels = 6144;   // small_max_panels: largest corpus (in 32-row panels) the single-launch path takes
+    int no_small = 0;        // scan_no_small = 1: corpora of 1025 rows .. 64 K rows take the general path also for few queries
+    int zero_copy = 1;       // zero_copy = 0: the synchronous host API copies queries / results instead of mapping them
+    int wide_waves = 0;      // wide_waves = 4 | 8: waves per workgroup of the wide kernel at 768-d (0 = the measured default)
+    int merge_in_scan = -1;  // merge_in_scan = 0 | 1: candidate merge by the scan's last workgroups instead of a launch of its own (-1 = default)
+    int wide_abl = 0;        // development builds only
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     // A row shard that took incremental appends holds several runs of consecutive global ids (cmr_index_set_id_blocks): the
     // kernels then run with base 0 and a remap launch translates their ids; candidate / row ids coming IN are translated
@@ -164,11 +167,11 @@ struct cmr_index {
     std::vector<long long> blk_local, blk_global;
     long long* d_blk = nullptr;          // [local0[nb] | global0[nb]] on the device
     std::vector<void*> blk_retired;      // earlier tables: in-flight searches may still read them (a few bytes each, freed at destroy)
-    int sample_maxmul = 0;   // CMR_SAMPLE_MAXMUL: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
-    int sample_div = 32;     // CMR_SAMPLE_DIV: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
-    int pipe_slots = 3;      // CMR_PIPE_SLOTS (2..4): batches in the pipeline.  A third slot lets the pre-phase of batch i+2 start before
+    int sample_maxmul = 0;   // sample_maxmul: level-1 sample <= sample_maxmul x level 0 (0 = 128 narrow / 512 wide)
+    int sample_div = 32;     // sample_div: level-1 sample = 1/sample_div of the panels (clamped to [8, 128] x level 0)
+    int pipe_slots = 3;      // pipe_slots (2..4): batches in the pipeline.  A third slot lets the pre-phase of batch i+2 start before
                              // scan i has ended: 1 M x 768 bf16, B = 64 step 0.279 -> 0.264 ms; nothing at 10 M rows
-    int reserve_cus = -1;    // CMR_PIPE_RESERVE_CUS: CUs the pipelined main scan leaves free (-1 = by corpus size, see enqueue_pass)
+    int reserve_cus = -1;    // pipe_reserve_cus: CUs the pipelined main scan leaves free (-1 = by corpus size, see enqueue_pass)
     std::mutex pipe_mu;
     Pipe pipe;
     size_t panel_bytes() const { return (size_t)CMR_PANEL_ROWS * dpad * elem_size(dtype); }
@@ -176,10 +179,48 @@ struct cmr_index {
 
 namespace {
 
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
+// Route selectors of an index (cmr_index_set_option).  Every one of them picks between implementations that return the
+// SAME results; they exist so that tests can hold the routes against each other and tools can A/B a kernel decision.
+int set_option(cmr_index* idx, const char* name, long long v) {
+    const std::string n(name ? name : "");
+    if (n == "scan_ring") idx->force_ring = (int)v;
+    else if (n == "scan_asm_ring") idx->force_asm = (int)v;
+    else if (n == "scan_grid") idx->force_grid = (int)v;
+    else if (n == "scan_no_sample") idx->no_sample = (int)v;
+    else if (n == "scan_no_wide") idx->no_wide = (int)v;
+    else if (n == "scan_no_tiny") idx->no_tiny = (int)v;
+    else if (n == "scan_no_small") idx->no_small = (int)v;
+    else if (n == "small_max_panels") idx->small_max_panels = (int)std::max<long long>(32, std::min<long long>(v, 6144));
+    else if (n == "tiny_multi") idx->tiny_multi = (int)v;
+    else if (n == "zero_copy") idx->zero_copy = (int)v;
+    else if (n == "sample_single") idx->single_level = (int)v;
+    else if (n == "sample_div") idx->sample_div = (int)std::max<long long>(2, v);
+    else if (n == "sample_maxmul") idx->sample_maxmul = (int)std::max<long long>(0, v);
+    else if (n == "pipe_reserve_cus") idx->reserve_cus = (int)v;
+    else if (n == "pipe_slots") idx->pipe_slots = (int)v;
+    else if (n == "wide_waves") { if (v != 0 && v != 4 && v != 8) return fail(CMR_ERR_INVALID, "wide_waves must be 0 (default), 4 or 8"); idx->wide_waves = (int)v; }
+    else if (n == "merge_in_scan") idx->merge_in_scan = (int)v;
+#ifdef CMR_DEV_KNOBS
+    else if (n == "wide_abl") idx->wide_abl = (int)v;      // ablation kernels: results are WRONG by design (development builds only)
+#endif
+    else return fail(CMR_ERR_INVALID, "unknown option '%s'", n.c_str());
+    return CMR_OK;
 }
+
+#ifdef CMR_DEV_KNOBS
+// development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
+void options_from_env(cmr_index* idx) {
+    static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "pipe_slots", "wide_waves", "merge_in_scan", "wide_abl"};
+    for (const char* nm : names) {
+        std::string env = "CMR_";
+        for (const char* c = nm; *c; ++c) env += (char)toupper(*c);
+        const char* v = getenv(env.c_str());
+        if (v && *v) (void)set_option(idx, nm, atoll(v));
+    }
+}
+#endif
 
 // id base the kernels add themselves (0 when a block table translates afterwards)
 long long kernel_id_base(const cmr_index* idx) { return idx->blk_local.size() > 1 ? 0 : idx->id_base; }
@@ -356,12 +397,14 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
                  hipEvent_t ev_lists_free, const float* q_dev, int nqp,
                  int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false,
                  const float* min_score = nullptr) {
-    CmrScanGeom g;
+    CmrScanGeom g{};
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
     int rc = arm_flag(ws, sp);   // zeroed once; the reader re-arms it after reporting
     if (rc) return rc;
     rc = make_geom(idx, nqp, k, true, &g);
     if (rc) return rc;
+    g.wide_waves = idx->wide_waves;
+    g.wide_abl = idx->wide_abl;
     const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
     // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
     // best of that sample per query as the threshold of the next level / of the main scan.  Any
@@ -621,7 +664,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
 
 int scores_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, float* out_dev, long long ld) {
     hipStream_t s = ws->stream;
-    CmrScanGeom g;
+    CmrScanGeom g{};
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int per_pass = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
@@ -781,21 +824,9 @@ int32_t cmr_index_create(int32_t device_id, int32_t dim, int32_t dtype, int64_t 
     idx->flags = flags;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) idx->n_cu = prop.multiProcessorCount;
-    idx->force_ring = env_int("CMR_SCAN_RING", 0);
-    idx->force_asm = env_int("CMR_SCAN_ASM_RING", -1);
-    idx->force_grid = env_int("CMR_SCAN_GRID", 0);
-    idx->no_sample = env_int("CMR_SCAN_NO_SAMPLE", 0);
-    idx->no_wide = env_int("CMR_SCAN_NO_WIDE", 0);
-    idx->zero_copy = env_int("CMR_ZERO_COPY", 1);
-    idx->tiny_multi = env_int("CMR_TINY_MULTI", 1);
-    idx->no_small = env_int("CMR_SCAN_NO_SMALL", 0);
-    idx->small_max_panels = env_int("CMR_SMALL_MAX_PANELS", 6144);
-    idx->single_level = env_int("CMR_SAMPLE_SINGLE", 1);
-    idx->no_tiny = env_int("CMR_SCAN_NO_TINY", 0);
-    idx->reserve_cus = env_int("CMR_PIPE_RESERVE_CUS", -1);
-    idx->pipe_slots = env_int("CMR_PIPE_SLOTS", 3);
-    idx->sample_div = std::max(2, env_int("CMR_SAMPLE_DIV", 32));
-    idx->sample_maxmul = std::max(0, env_int("CMR_SAMPLE_MAXMUL", 0));
+#ifdef CMR_DEV_KNOBS
+    options_from_env(idx);
+#endif
     if (cmr_scan_max_nqt(dtype, idx->dpad) == 0) {
         delete idx;
         return fail(CMR_ERR_UNSUPPORTED, "dim %d (padded %d) exceeds the LDS-resident query tile for dtype %d", dim, round_up(dim, 128), dtype);
@@ -993,6 +1024,12 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
     idx->blk_global.assign(global_start, global_start + n_blocks);
     idx->id_base = global_start[0];
     return CMR_OK;
+}
+
+int32_t cmr_index_set_option(cmr_index_t* idx, const char* name, int64_t value) {
+    if (!idx || !name) return fail(CMR_ERR_INVALID, "NULL argument");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    return set_option(idx, name, value);
 }
 
 int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream) {

@@ -16,6 +16,8 @@ struct CmrScanGeom {
     int grid;       // workgroups
     int asm_ring;   // 1: hand-counted inline-asm load ring, 0: compiler-counted loads
     size_t lds;     // dynamic LDS bytes
+    int wide_waves; // wide kernel at 768-d: 0 = default, 4 = one wave per SIMD x 2 tiles, 8 = two waves per SIMD x 1 tile
+    int wide_abl;   // development builds only (-DCMR_DEV_KNOBS): ablation variant of the wide kernel
 };
 
 // max query tiles (1/2/0=unsupported) whose fragments fit LDS for this dtype/dpad
@@ -52,7 +54,7 @@ hipError_t cmr_launch_scan_scores(const CmrScanGeom& g, const CmrScanArgs& a, hi
 // in sampling mode (sample_waves > 0) the grid's workgroups split the sample_waves strided panels among them
 hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
 int cmr_wide_queries(int dtype, int dpad);      // queries per pass of the wide kernel (0 = unavailable)
-size_t cmr_wide_lds_bytes(int ks, int cap);
+size_t cmr_wide_lds_bytes(int ks, int cap, int waves);
 
 // queries fp32 [nq, dim] (device) -> fragment-ordered blocks of the index dtype, zero padded
 hipError_t cmr_launch_prep_queries(int dtype, const float* q, int nq, int dim, int dpad, int nqt,

@@ -431,7 +431,12 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 // counter rows are laid out [workgroup][4*NT*32 queries] so merge_query_kernel consumes them with
 // W = gridDim.x.
 #define WIDE_WAVES 4
+#ifndef WIDE_GROUP
 #define WIDE_GROUP 16     // blocks per staged group
+#endif
+#ifndef WIDE4_NST
+#define WIDE4_NST 8       // stages of the LDS ring (4-wave kernel): WIDE4_NST x WIDE_GROUP KiB, one stage being refilled
+#endif
 #define WIDE_ADEPTH 8     // LDS read-ahead ring of a wave, in blocks (two quads: one in use, one landing)
 
 // Epilogue pieces of the wide kernel.  The wave's register file is full of query fragments, and hipcc's allocator
@@ -510,9 +515,20 @@ __device__ __forceinline__ float wide_minmax_partial(const f32x16& acc, int nval
 //  * 32-bit rows.  Everything derived from the lane id is made opaque here: hipcc would otherwise hoist sixteen
 //    per-register row offsets and the list pointers out of the panel loop, as loop-invariant values that then live
 //    across the whole scan (and evict query fragments).
-#define WIDE_STG 256      // staging records (16 B) per wave
+#ifndef WIDE_STG
+#define WIDE_STG 256      // staging records (16 B) per wave (4-wave kernel)
+#endif
+// 8-wave kernel: k-steps of a tile whose B-operand is served from LDS instead of a register (the wave has 256 registers:
+// 192 of fragments + 16 accumulators + a 16-register read-ahead ring leave hipcc too few for everything else)
+#ifndef WIDE8_KLDS
+#define WIDE8_KLDS 4
+#endif
+#ifndef WIDE8_NST
+#define WIDE8_NST 6
+#endif
+#define WIDE8_STG 64
 #define WIDE_AMOVE 8      // NT = 2: k-steps of tile 0 whose B-operand lives in the AGPR half
-template <int CAP>
+template <int CAP, int STG>
 __device__ __forceinline__ u64 wide_push(const f32x16& acc, unsigned row0, int nvalid, float tau_f, int* cnt_t, u64* list_t, uint4* stg,
                                          int* stg_tail, int lane, int& n_stores) {
     int ql = lane & 31;
@@ -534,7 +550,7 @@ __device__ __forceinline__ u64 wide_push(const f32x16& acc, unsigned row0, int n
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int T = __builtin_amdgcn_readfirstlane(*stg_tail);
-    if (T <= WIDE_STG) {
+    if (T <= STG) {
         unsigned dsti = (unsigned)ql * CAP + (unsigned)slot;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -662,45 +678,73 @@ __device__ __forceinline__ void wide_compact(u64 need, int k, u64& tau_key, floa
     }
 }
 
-// ABL: developer ablations (CMR_WIDE_ABL, results are wrong by design): 1 no MFMA, 2 no DMA in the loop, 3 no epilogue,
+// ABL: developer ablations (development builds, -DCMR_DEV_KNOBS, option "wide_abl"; results are wrong by design): 1 no MFMA, 2 no DMA in the loop, 3 no epilogue,
 // 4 min/max but no threshold test / slow path, 5 no barrier in the loop, 6 = 2 + no LDS reads, 7 = 2 + no barrier
-template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS, int ABL = 0>
-__global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) {
-    constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = WIDE_ADEPTH;
-    static_assert(KS % GRP == 0 && GRP % WIDE_WAVES == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && GRP / 4 == GRP / WIDE_WAVES && NST >= 4, "group geometry");
+// NW = waves per workgroup.  4: one wave per SIMD, the whole 512-entry register file, NT = 2 tiles per wave at 768-d.
+// 8: TWO waves per SIMD (256 registers each), one tile per wave (192 registers of fragments at 768-d) — the same 256 queries
+// per workgroup, but every SIMD now has a partner wave whose MFMAs fill the matrix pipe while the other runs its epilogue
+// or sits at a wait / barrier; the price is that every block is read from LDS by eight waves instead of four (128 B/clk of
+// the LDS's 256 B/clk ds_read_b128 rate at full MFMA rate, guide §LDS) and a 4-block read-ahead ring instead of 8.
+template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS, int ABL = 0, int NW = WIDE_WAVES>
+__global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
+    constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = NW == 8 ? 4 : WIDE_ADEPTH;
+    constexpr int STG = NW == 8 ? WIDE8_STG : WIDE_STG;         // staging records per wave (LDS budget)
+    static_assert(NW == 4 || (NW == 8 && NT == 1), "8 waves hold one tile each");
+    static_assert(KS % GRP == 0 && GRP % NW == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && NST >= 4, "group geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NQB = WIDE_WAVES * NT * 32;     // queries per workgroup pass
+    constexpr int NQB = NW * NT * 32;             // queries per workgroup pass
     constexpr int GPP = KS / GRP;                 // groups per panel
-    constexpr int PPG = GRP / WIDE_WAVES;         // DMA pieces per wave per group
-    static_assert(GRP / PPG == 4, "one DMA piece per quad of blocks");
+    constexpr int PPG = GRP / NW;                 // DMA pieces per wave per group
+    constexpr int QPP = (GRP / 4) / PPG;          // quads of blocks per DMA piece of a wave (1 at 4 waves, 2 at 8)
+    static_assert(PPG * QPP == GRP / 4, "DMA pieces spread evenly over the quads of a group");
     constexpr int KREG = KS - KLDS;               // k-steps of a tile resident in registers; the last KLDS sit in LDS
+    constexpr int VK = NW == 8 ? (KS - KLDS) - 28 : KS / 2;     // NT = 1: k-steps whose B-operand lives in the VGPR half (the rest: AGPRs; hipcc splits a 256-register budget 128 / 128: 16 accumulators + 28 k-steps fill the AGPR half exactly)
 
     v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][GRP][64]
     int* cnt_all = reinterpret_cast<int*>(smem + NST * GRP * 1024);                   // [NQB]
     u64* cstage_all = reinterpret_cast<u64*>(cnt_all + NQB);                          // [WAVES][CAP+2]
-    v4u* qlds_all = reinterpret_cast<v4u*>(cstage_all + WIDE_WAVES * (CAP + 2));     // [WAVES][NT][KLDS][64]
-    uint4* stg_all = reinterpret_cast<uint4*>(qlds_all + (size_t)WIDE_WAVES * NT * KLDS * 64);   // [WAVES][WIDE_STG] staging records
-    int* tail_all = reinterpret_cast<int*>(stg_all + (size_t)WIDE_WAVES * WIDE_STG);  // [WAVES]
+    v4u* qlds_all = reinterpret_cast<v4u*>(cstage_all + NW * (CAP + 2));             // [WAVES][NT][KLDS][64]
+    uint4* stg_all = reinterpret_cast<uint4*>(qlds_all + (size_t)NW * NT * KLDS * 64);   // [WAVES][STG] staging records
+    int* tail_all = reinterpret_cast<int*>(stg_all + (size_t)NW * STG);               // [WAVES]
     v4u* qlds = qlds_all + (size_t)wave * NT * KLDS * 64 + lane;
-    uint4* stg = stg_all + (size_t)wave * WIDE_STG;
+    uint4* stg = stg_all + (size_t)wave * STG;
     int* stg_tail = tail_all + wave;
     int* cnt_w = cnt_all + wave * NT * 32;
     u64* cstage = cstage_all + wave * (CAP + 2);
-    for (int i = tid; i < NQB; i += WIDE_WAVES * 64) cnt_all[i] = 0;
+    for (int i = tid; i < NQB; i += NW * 64) cnt_all[i] = 0;
 
     // this wave's query fragments -> registers (static indices everywhere below)
     v4u qreg[NT][KREG];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
+    if constexpr (NW == 8) {
+        // 256 registers per wave: the fragment loads are inline asm with a wave-uniform SGPR base, one lane offset and the
+        // destination's register file fixed by the constraint — compiler-generated loads build a 64-bit VGPR address per
+        // few fragments, and that prologue peak alone spills fragments for the whole kernel
+        const unsigned loff = (unsigned)lane * 16u;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const v4u v = P.qfrag[((size_t)(wave * NT + t) * KS + ks) * 64 + lane];
-            if (ks < KREG) qreg[t][ks < KREG ? ks : 0] = v;
-            else qlds[(t * KLDS + (ks - KREG)) * 64] = v;        // written and read by the same lane only
+            const char* qb = reinterpret_cast<const char*>(P.qfrag) + ((size_t)wave * KS + (size_t)(ks & ~3)) * 1024;   // wave-uniform
+            if (ks < KREG) {
+                if (ks >= VK) asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(qreg[0][ks < KREG ? ks : 0]) : "v"(loff), "s"(qb), "n"((ks & 3) * 1024) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(qreg[0][ks < KREG ? ks : 0]) : "v"(loff), "s"(qb), "n"((ks & 3) * 1024) : "memory");
+            } else {
+                v4u v;
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(loff), "s"(qb), "n"((ks & 3) * 1024) : "memory");
+                qlds[(ks - KREG) * 64] = v;                       // written and read by the same lane only
+            }
         }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v4u v = P.qfrag[((size_t)(wave * NT + t) * KS + ks) * 64 + lane];
+                if (ks < KREG) qreg[t][ks < KREG ? ks : 0] = v;
+                else qlds[(t * KLDS + (ks - KREG)) * 64] = v;        // written and read by the same lane only
+            }
+    }
     // Make hipcc retire every query-fragment load HERE: left alone it defers each wait to the
     // fragment's first use inside the panel loop, where stale low-count s_waitcnt vmcnt(N) would
     // drain the hand-counted DMA ring on every iteration.
@@ -753,7 +797,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
             const int dp = s0 + d / GPP;
             const char* src = dp < s1 ? panel_src(dp) + (d % GPP) * GRP * 1024 : last_group;
 #pragma unroll
-            for (int j = 0; j < PPG; ++j) dma_piece(src + j * WIDE_WAVES * 1024, lds_base + (unsigned)(d * GRP + j * WIDE_WAVES) * 1024u);
+            for (int j = 0; j < PPG; ++j) dma_piece(src + j * NW * 1024, lds_base + (unsigned)(d * GRP + j * NW) * 1024u);
         }
         // group 0 must be complete before the first reads; from then on the barrier of group g validates
         // group g+1, so the LDS read-ahead never has to stop at a group or panel boundary
@@ -797,7 +841,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                 if constexpr (decltype(folded)::value) asm volatile("" : "+a"(acc[t]));
                 // sampling pass: dense hits (threshold from a small sample) -> staged push; main pass: sparse hits
                 const u64 need = P.sample_waves > 0
-                    ? wide_push<CAP>(acc[t], row0, nvalid, tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, stg, stg_tail, lane, n_stores)
+                    ? wide_push<CAP, STG>(acc[t], row0, nvalid, tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, stg, stg_tail, lane, n_stores)
                     : wide_push_sparse<CAP, decltype(folded)::value>(acc[t], eg, row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane, n_stores);
                 if (need) {
                     wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
@@ -833,9 +877,9 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                     if (ABL != 2 && ABL != 6 && ABL != 7) {
                         if (CMR_WIDE_DMA_BURST) {
                             if (qd == 0)
-                                for (int j = 0; j < PPG; ++j) dma_piece(dsrc + j * WIDE_WAVES * 1024, ddst + (unsigned)j * WIDE_WAVES * 1024u);
-                        } else {
-                            dma_piece(dsrc + qd * WIDE_WAVES * 1024, ddst + (unsigned)qd * WIDE_WAVES * 1024u);
+                                for (int j = 0; j < PPG; ++j) dma_piece(dsrc + j * NW * 1024, ddst + (unsigned)j * NW * 1024u);
+                        } else if (qd % QPP == 0) {
+                            dma_piece(dsrc + (qd / QPP) * NW * 1024, ddst + (unsigned)(qd / QPP) * NW * 1024u);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -849,7 +893,7 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
                             // register file of the resident B-operand: tile 0 in VGPRs, tile 1 in AGPRs (NT = 2); first /
                             // second half of the k-steps (NT = 1).  The accumulators are AGPRs.
                             // (WIDE_AMOVE of tile 0's operands also sit in AGPRs: the AGPR half has registers to spare)
-                            const int ab = NT == 2 ? (t == 1 || ks >= KS - WIDE_AMOVE ? 1 : 0) : (ks >= KS / 2 ? 1 : 0);
+                            const int ab = NT == 2 ? (t == 1 || ks >= KS - WIDE_AMOVE ? 1 : 0) : (ks >= VK ? 1 : 0);
                             if constexpr (ABL == 1) {
                                 if (ab) asm volatile("" ::"v"(a_use), "a"(qreg[t][ks < KREG ? ks : 0]));
                                 else asm volatile("" ::"v"(a_use), "v"(qreg[t][ks < KREG ? ks : 0]));
@@ -919,7 +963,16 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
             bool compacted = false;
             if constexpr (NT == 1) {
                 cmr_mfma_drain<NT>(acc);          // MFMA results -> VALU readers: wait states hipcc does not insert for asm
-                epi_finish(T0{}, std::false_type{}, row0, nvalid, n_stores, compacted);
+                if constexpr (NW == 8) {
+                    // 256 registers per wave: the fold takes the accumulators four at a time through asm reads (wide_epi_piece)
+                    // and the slow path re-reads what it needs — sixteen scores held in VGPRs from the fold to the push do not fit
+                    emn = __builtin_inff();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wide_epi_piece(acc[0], j, eg[j], emn);
+                    epi_finish(T0{}, std::true_type{}, row0, nvalid, n_stores, compacted);
+                } else {
+                    epi_finish(T0{}, std::false_type{}, row0, nvalid, n_stores, compacted);
+                }
                 st_old = st_new;
                 st_new = __builtin_amdgcn_readfirstlane(n_stores);
                 if (compacted) {        // its loads already drained the ring; retire its stores too and restart the count
@@ -962,23 +1015,33 @@ __global__ __launch_bounds__(WIDE_WAVES * 64, 1) void scan_wide_kernel(ScanP P) 
     }
 }
 
-// geometry of the wide kernel per shape: query tiles per wave, LDS ring depth, k-steps of a tile served from LDS
-static int wide_nt(int ks) { return ks == 48 ? 2 : 1; }
-#define WIDE_NST_48 8
-#define WIDE_KLDS_48 0
-#define WIDE_NST_64 8
-#define WIDE_KLDS_64 0
-
-size_t cmr_wide_lds_bytes(int ks, int cap) {
-    const int nt = wide_nt(ks);
-    const int nst = ks == 48 ? WIDE_NST_48 : WIDE_NST_64;
-    const int klds = ks == 48 ? WIDE_KLDS_48 : WIDE_KLDS_64;
-    return (size_t)nst * WIDE_GROUP * 1024 + (size_t)WIDE_WAVES * nt * 32 * 4 + (size_t)WIDE_WAVES * (cap + 2) * 8 +
-           (size_t)WIDE_WAVES * nt * klds * 1024 + (size_t)WIDE_WAVES * WIDE_STG * 16 + WIDE_WAVES * 4;
+// geometry of the wide kernel per shape: waves per workgroup, query tiles per wave, LDS ring depth
+struct WideCfg { int nw, nt, nst, stg, klds; };
+// Default waves per workgroup at 768-d (ks = 48): measured A/B on MI355X, 10 M x 768 bf16, B = 256 (profiles/r3_wide_ab.txt)
+#ifndef CMR_WIDE_DEFAULT_WAVES
+#define CMR_WIDE_DEFAULT_WAVES 4
+#endif
+static WideCfg wide_cfg(int ks, int cap, int waves) {
+    if (ks == 48) {
+        if (waves == 0) waves = CMR_WIDE_DEFAULT_WAVES;
+        // 8 waves: 16 KiB of staging + 8 compaction stages next to the ring -> 7 stages of 16 KiB for the 256-entry lists
+#ifdef CMR_WIDE8
+        if (waves == 8) return {8, 1, cap > 128 ? WIDE8_NST - 1 : WIDE8_NST, WIDE8_STG, WIDE8_KLDS};
+#endif
+        return {4, 2, WIDE4_NST, WIDE_STG, 0};
+    }
+    return {4, 1, WIDE4_NST, WIDE_STG, 0};
 }
 
-// wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 4 waves x 2 tiles x 32 = 256 queries per pass),
-// ks = 64 (1024-d: a tile needs 256 registers -> 4 waves x 1 tile x 32 = 128 queries per pass)
+size_t cmr_wide_lds_bytes(int ks, int cap, int waves) {
+    const WideCfg c = wide_cfg(ks, cap, waves);
+    return (size_t)c.nst * WIDE_GROUP * 1024 + (size_t)c.nw * c.nt * 32 * 4 + (size_t)c.nw * (cap + 2) * 8 + (size_t)c.nw * c.nt * c.klds * 1024 +
+           (size_t)c.nw * c.stg * 16 + c.nw * 4;
+}
+
+// wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 256 queries per pass — 4 waves x 2 tiles or 8 waves x 1 tile of 32),
+// ks = 64 (1024-d: a tile needs 256 registers -> 4 waves x 1 tile x 32 = 128 queries per pass).  Any other padded dim, and
+// fp32 indexes, run batches of more than 64 queries as ceil(B / 64) passes of the narrow kernel.
 int cmr_wide_queries(int dtype, int dpad) {
     if (dtype == CMR_DT_F32) return 0;
     if (dpad == 768) return 256;
@@ -988,28 +1051,43 @@ int cmr_wide_queries(int dtype, int dpad) {
 
 hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
     const ScanP p = to_p(g, a);
-    const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap);
+    const WideCfg c = wide_cfg(g.ks, g.cap, g.wide_waves);
+    const size_t lds = cmr_wide_lds_bytes(g.ks, g.cap, g.wide_waves);
     auto launch = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(WIDE_WAVES * 64), lds, s, p);
+        hipLaunchKernelGGL(kern, dim3(g.grid), dim3(c.nw * 64), lds, s, p);
         return hipGetLastError();
     };
-    const int abl = getenv("CMR_WIDE_ABL") ? atoi(getenv("CMR_WIDE_ABL")) : 0;
-    if (abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128) {
-        if (abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 1>);
-        if (abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 2>);
-        if (abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 3>);
-        if (abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 4>);
-        if (abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 5>);
-        if (abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 6>);
-        if (abl == 7) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48, 7>);
+#ifdef CMR_DEV_KNOBS
+    // development builds: ablation kernels (results are wrong by design) behind the "wide_abl" option
+    if (g.wide_abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128 && c.nw == 4) {
+        if (g.wide_abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 1>);
+        if (g.wide_abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 2>);
+        if (g.wide_abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 3>);
+        if (g.wide_abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 4>);
+        if (g.wide_abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 5>);
+        if (g.wide_abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 6>);
+        if (g.wide_abl == 7) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 7>);
     }
-#define WCASE(DT, KSV, NTV, CAPV, NSTV, KLV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV) return launch(scan_wide_kernel<DT, KSV, NTV, CAPV, NSTV, KLV>);
-    WCASE(CMR_DT_BF16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48) WCASE(CMR_DT_BF16, 48, 2, 256, WIDE_NST_48, WIDE_KLDS_48)
-    WCASE(CMR_DT_F16, 48, 2, 128, WIDE_NST_48, WIDE_KLDS_48) WCASE(CMR_DT_F16, 48, 2, 256, WIDE_NST_48, WIDE_KLDS_48)
-    WCASE(CMR_DT_BF16, 64, 1, 128, WIDE_NST_64, WIDE_KLDS_64) WCASE(CMR_DT_BF16, 64, 1, 256, WIDE_NST_64, WIDE_KLDS_64)
-    WCASE(CMR_DT_F16, 64, 1, 128, WIDE_NST_64, WIDE_KLDS_64) WCASE(CMR_DT_F16, 64, 1, 256, WIDE_NST_64, WIDE_KLDS_64)
+#endif
+#if defined(CMR_DEV_KNOBS) && defined(CMR_WIDE8)
+    if (g.wide_abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128 && c.nw == 8) {
+        if (g.wide_abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 1, 128, WIDE8_NST, WIDE8_KLDS, 1, 8>);
+        if (g.wide_abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 1, 128, WIDE8_NST, WIDE8_KLDS, 2, 8>);
+        if (g.wide_abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 1, 128, WIDE8_NST, WIDE8_KLDS, 3, 8>);
+        if (g.wide_abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 1, 128, WIDE8_NST, WIDE8_KLDS, 5, 8>);
+    }
+#endif
+#define WCASE(DT, KSV, NTV, CAPV, NSTV, NWV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV && c.nw == NWV) return launch(scan_wide_kernel<DT, KSV, NTV, CAPV, NSTV, (NWV == 8 ? WIDE8_KLDS : 0), 0, NWV>);
+    WCASE(CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 4) WCASE(CMR_DT_BF16, 48, 2, 256, WIDE4_NST, 4)
+    WCASE(CMR_DT_F16, 48, 2, 128, WIDE4_NST, 4) WCASE(CMR_DT_F16, 48, 2, 256, WIDE4_NST, 4)
+#ifdef CMR_WIDE8     // experimental: two waves per SIMD, one tile each (hipcc does not yet fit it into 256 registers without spills)
+    WCASE(CMR_DT_BF16, 48, 1, 128, WIDE8_NST, 8) WCASE(CMR_DT_BF16, 48, 1, 256, WIDE8_NST - 1, 8)
+    WCASE(CMR_DT_F16, 48, 1, 128, WIDE8_NST, 8) WCASE(CMR_DT_F16, 48, 1, 256, WIDE8_NST - 1, 8)
+#endif
+    WCASE(CMR_DT_BF16, 64, 1, 128, WIDE4_NST, 4) WCASE(CMR_DT_BF16, 64, 1, 256, WIDE4_NST, 4)
+    WCASE(CMR_DT_F16, 64, 1, 128, WIDE4_NST, 4) WCASE(CMR_DT_F16, 64, 1, 256, WIDE4_NST, 4)
 #undef WCASE
     return hipErrorInvalidValue;
 }

@@ -29,7 +29,7 @@ def _ptr(a: np.ndarray) -> int:
 
 class DenseIndex:
     def __init__(self, dim: int, dtype: str = "bf16", device: int = 0, capacity_hint: int = 0,
-                 keep_f32: bool = False):
+                 keep_f32: bool = False, options: Optional[dict] = None):
         self._h = C.c_void_p()
         self.dim = int(dim)
         self.dtype = dtype
@@ -37,6 +37,12 @@ class DenseIndex:
         self.keep_f32 = bool(keep_f32)
         L.check(L.lib().cmr_index_create(self.device, self.dim, L.DTYPES[dtype], int(capacity_hint),
                                          L.CMR_FLAG_KEEP_F32 if keep_f32 else 0, C.byref(self._h)))
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name: str, value: int) -> None:
+        """Route selector (cmr_index_set_option): picks between implementations that return the same results."""
+        L.check(L.lib().cmr_index_set_option(self._h, name.encode(), int(value)))
 
     # -- lifetime
     def close(self) -> None:

@@ -139,6 +139,15 @@ int32_t cmr_index_set_id_base(cmr_index_t* idx, int64_t base);
  * when there is more than one block), cmr_index_rescore / cmr_index_get_rows translate the ids they are given.  Global
  * ids must stay < 2^32 - 1 (the packed candidate exchange carries 32-bit rows): checked here and by append.            */
 int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_t* local_start, const int64_t* global_start);
+/* Route selectors.  Each option picks between implementations that return the SAME results (the tests hold the routes
+ * against each other bit for bit; tools A/B kernel decisions with them).  Nothing is read from the environment by the
+ * shipped library.  Names: scan_ring (8 | 16), scan_asm_ring (0 | 1), scan_grid, scan_no_sample, scan_no_wide (batches of
+ * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
+ * paths), zero_copy, sample_single, sample_div, sample_maxmul, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
+ * waves per workgroup of the batch-256 kernel at 768-d), merge_in_scan (0 | 1).  Unknown names: CMR_ERR_INVALID.
+ * The wide-batch kernel exists for padded dims 768 (256 queries per pass) and 1024 (128 per pass) in bf16 / f16; any other
+ * dim and every fp32 index run a batch of B > 64 queries as ceil(B / 64) passes of the narrow kernel — same results.       */
+int32_t cmr_index_set_option(cmr_index_t* idx, const char* name, int64_t value);
 /* The pipeline's streams (which = 0 pre-phase, 1 main scans, 2 candidate merges / outputs) as
  * hipStream_t.  Work enqueued on stream 2 after a pipelined call is ordered after that call's
  * outputs and before the next use of the same output buffers (the RCCL exchange goes there).     */

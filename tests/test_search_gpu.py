@@ -22,20 +22,11 @@ def _mk(n, d, nq, seed=0):
 
 def _check(index_dtype, X, Q, k, env=None):
     from comorag_amd.index import DenseIndex
-    old = {}
-    for kk, v in (env or {}).items():
-        old[kk] = os.environ.get(kk)
-        os.environ[kk] = v
-    try:
-        idx = DenseIndex(X.shape[1], index_dtype)
-        idx.append(X)
-        ids, sc, mn, mx = idx.search(Q, k)
-    finally:
-        for kk, v in old.items():
-            if v is None:
-                os.environ.pop(kk, None)
-            else:
-                os.environ[kk] = v
+    # `env` names a route the library would not pick by itself ("CMR_SCAN_NO_WIDE": "1" = option scan_no_wide = 1): the
+    # shipped library reads nothing from the environment, the options go through cmr_index_set_option
+    idx = DenseIndex(X.shape[1], index_dtype, options={kk[4:].lower(): int(v) for kk, v in (env or {}).items()})
+    idx.append(X)
+    ids, sc, mn, mx = idx.search(Q, k)
     rnd = ROUND[index_dtype]
     exact = orc.exact_scores_f64(rnd(X), rnd(Q))
     ref_ids, ref_sc = orc.topk_rule(exact, k)
@@ -104,22 +95,16 @@ def test_scores_single_launch_equals_general_path(dtype, n, d, nq):
     from comorag_amd.index import DenseIndex
     X, Q = _mk(n, d, nq, seed=n % 991 + nq)
     outs = []
-    for env in ({}, {"CMR_SCAN_NO_SMALL": "1"}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
-            idx = DenseIndex(d, dtype)
-            idx.append(X)
-            outs.append(idx.scores(Q))
-            if not env:
-                bad = Q.copy(); bad[0, 1] = np.inf
-                with pytest.raises(_lib.CmrError):
-                    idx.scores(bad)
-                assert np.array_equal(idx.scores(Q), outs[0])
-            idx.close()
-        finally:
-            for k, v in old.items():
-                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for opts in ({}, {"scan_no_small": 1}):
+        idx = DenseIndex(d, dtype, options=opts)
+        idx.append(X)
+        outs.append(idx.scores(Q))
+        if not opts:
+            bad = Q.copy(); bad[0, 1] = np.inf
+            with pytest.raises(_lib.CmrError):
+                idx.scores(bad)
+            assert np.array_equal(idx.scores(Q), outs[0])
+        idx.close()
     assert outs[0].shape == (nq, n) and np.array_equal(outs[0], outs[1])
     rnd = ROUND[dtype]
     np.testing.assert_allclose(outs[0], orc.exact_scores_f64(rnd(X), rnd(Q)), atol=ERR, rtol=0)

@@ -1,0 +1,13 @@
+"""Development tools (GPU box).  The shipped library reads nothing from the environment; the tools translate their
+CMR_<OPTION> environment variables into cmr_index_set_option calls (`options=env_options()`).  `wide_abl` exists only in a
+development build: CMR_EXTRA_HIPCC_FLAGS=-DCMR_DEV_KNOBS CMR_BUILD_LIB=/path/libdev.so python -m comorag_amd.build, then
+COMORAG_HIP_LIB=/path/libdev.so."""
+import os
+
+OPTION_NAMES = ("scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small", "small_max_panels",
+                "tiny_multi", "zero_copy", "sample_single", "sample_div", "sample_maxmul", "pipe_reserve_cus", "pipe_slots", "wide_waves",
+                "merge_in_scan", "wide_abl")
+
+
+def env_options() -> dict:
+    return {n: int(os.environ["CMR_" + n.upper()]) for n in OPTION_NAMES if os.environ.get("CMR_" + n.upper(), "") != ""}

@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from comorag_amd.index import DenseIndex
+from tools import env_options
 batch, dim, k = 64, 768, 20
 rows_list = [int(x) for x in sys.argv[1].split(",")]
 reserves = [int(x) for x in sys.argv[2].split(",")]
@@ -17,7 +18,7 @@ for rows in rows_list:
     for rsv, qgl in [(r, g_) for g_ in qglobals for r in reserves]:
         os.environ["CMR_PIPE_RESERVE_CUS"] = str(rsv)
         os.environ["CMR_SAMPLE_DIV"] = str(qgl)
-        idx = DenseIndex(dim, "bf16", capacity_hint=rows)
+        idx = DenseIndex(dim, "bf16", capacity_hint=rows, options=env_options())
         for x in blocks: idx.append_dev(x)
         torch.cuda.synchronize()
         for i in range(20): h = idx.search_pipelined(q, k, outs[i & 1][0], outs[i & 1][1])

@@ -5,6 +5,7 @@ import os, sys, time, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from comorag_amd.index import DenseIndex
+from tools import env_options
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -25,7 +26,7 @@ for env in variants:
     for kk in ("CMR_SCAN_RING", "CMR_SCAN_ASM_RING", "CMR_SCAN_NO_SAMPLE", "CMR_SCAN_GRID", "CMR_SCAN_NO_WIDE", "CMR_PIPE_RESERVE_CUS", "CMR_WIDE_ABL"):
         os.environ.pop(kk, None)
     os.environ.update(env)
-    idx = DenseIndex(dim, "bf16", capacity_hint=rows)
+    idx = DenseIndex(dim, "bf16", capacity_hint=rows, options=env_options())
     g.manual_seed(2)
     for x in gen():
         idx.append_dev(x)

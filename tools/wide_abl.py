@@ -3,6 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from comorag_amd.index import DenseIndex
+from tools import env_options
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 dim, k, B = 768, 20, 256
 dev = torch.device("cuda", 0); g = torch.Generator(device=dev); g.manual_seed(7)
@@ -12,7 +13,7 @@ for b in range(0, rows, 250_000):
 q = torch.randn((B, dim), generator=g, device=dev); q = (q / q.norm(dim=1, keepdim=True)).contiguous()
 for abl in [int(a) for a in (sys.argv[2].split(",") if len(sys.argv) > 2 else "0,1,2,3,4,5".split(","))]:
     os.environ["CMR_WIDE_ABL"] = str(abl)
-    idx = DenseIndex(dim, "bf16", capacity_hint=rows)
+    idx = DenseIndex(dim, "bf16", capacity_hint=rows, options=env_options())
     for x in blocks: idx.append_dev(x)
     torch.cuda.synchronize()
     for _ in range(3): idx.search_dev(q, k)

@@ -5,6 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from comorag_amd.index import DenseIndex
+from tools import env_options
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 dim, k = 768, 20
@@ -18,7 +19,7 @@ ref = None
 for name, env in [("wide", {}), ("narrow passes", {"CMR_SCAN_NO_WIDE": "1"})]:
     os.environ.pop("CMR_SCAN_NO_WIDE", None)
     os.environ.update(env)
-    idx = DenseIndex(dim, "bf16", capacity_hint=rows)
+    idx = DenseIndex(dim, "bf16", capacity_hint=rows, options=env_options())
     for x in blocks: idx.append_dev(x)
     torch.cuda.synchronize()
     ids, sc = idx.search_dev(q, k); torch.cuda.synchronize()
