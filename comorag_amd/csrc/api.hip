@@ -1263,18 +1263,54 @@ int32_t cmr_index_sorted_scores(cmr_index_t* idx, const float* q, int32_t nq, in
     HIP_TRY(ws->d_q.ensure((size_t)nq * idx->dim * 4));
     HIP_TRY(ws->d_out.ensure((size_t)n * 4));
     HIP_TRY(ws->d_cand.ensure(cmr_sort_workspace_bytes(n)));
-    HIP_TRY(ws->d_ids.ensure((size_t)n * 8));
-    HIP_TRY(ws->d_scores.ensure((size_t)n * 4));
     HIP_TRY(hipMemcpyAsync(ws->d_q.p, q, (size_t)nq * idx->dim * 4, hipMemcpyHostToDevice, s));
+    // Several queries: scan + sort of query i + 1 run while the 12 N bytes of query i cross the link on a second stream
+    // (two result sets, two event pairs; one query: no second stream, no events).  Nothing synchronises per query.
+    const int nset = nq > 1 ? 2 : 1;
+    Workspace* wc = nset > 1 ? acquire_ws(idx, nullptr, false) : nullptr;      // its stream carries the copies
+    if (nset > 1 && !wc) return fail(CMR_ERR_HIP, "could not create a copy stream");
+    struct Rel2 { cmr_index* i; Workspace* w; ~Rel2() { if (w) release_ws(i, w); } } rel2{idx, wc};
+    DevBuf* ids_buf[2] = {&ws->d_ids, wc ? &wc->d_ids : nullptr};
+    DevBuf* sc_buf[2] = {&ws->d_scores, wc ? &wc->d_scores : nullptr};
+    hipEvent_t sorted[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+    struct Ev { hipEvent_t* a; hipEvent_t* b; ~Ev() { for (int i = 0; i < 2; ++i) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); } } } evs{sorted, copied};
+    for (int i = 0; i < nset; ++i) {
+        HIP_TRY(ids_buf[i]->ensure((size_t)n * 8));
+        HIP_TRY(sc_buf[i]->ensure((size_t)n * 4));
+        if (nset > 1) {
+            HIP_TRY(hipEventCreateWithFlags(&sorted[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+        }
+    }
+    hipStream_t sc = wc ? wc->stream : s;
+    auto copy_out = [&](int qi) -> int {         // a pageable destination may hold the calling thread until the copy is done:
+        const int b = qi % nset;                  // issued only AFTER the next query's scan + sort are in the queue
+        if (nset > 1) HIP_TRY(hipStreamWaitEvent(sc, sorted[b], 0));
+        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)qi * n, ids_buf[b]->p, (size_t)n * 8, hipMemcpyDeviceToHost, sc));
+        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)qi * n, sc_buf[b]->p, (size_t)n * 4, hipMemcpyDeviceToHost, sc));
+        if (nset > 1) HIP_TRY(hipEventRecord(copied[b], sc));
+        return CMR_OK;
+    };
+    auto body = [&]() -> int {
+        for (int qi = 0; qi < nq; ++qi) {
+            const int b = qi % nset;
+            if (nset > 1 && qi >= nset) HIP_TRY(hipStreamWaitEvent(s, copied[b], 0));      // the set's previous contents are on the host
+            int rc_ = scores_enqueue(idx, ws, (const float*)ws->d_q.p + (size_t)qi * idx->dim, 1, (float*)ws->d_out.p, n);
+            if (rc_) return rc_;
+            HIP_TRY(cmr_launch_sort_scores((const float*)ws->d_out.p, n, kernel_id_base(idx), ws->d_cand.p, (int64_t*)ids_buf[b]->p, (float*)sc_buf[b]->p, s));
+            rc_ = remap_ids_enqueue(idx, (int64_t*)ids_buf[b]->p, n, s);
+            if (rc_) return rc_;
+            if (nset > 1) HIP_TRY(hipEventRecord(sorted[b], s));
+            if (qi > 0) { rc_ = copy_out(qi - 1); if (rc_) return rc_; }
+        }
+        return copy_out(nq - 1);
+    };
+    rc = body();
+    const hipError_t e1 = hipStreamSynchronize(s);
+    const hipError_t e2 = sc != s ? hipStreamSynchronize(sc) : hipSuccess;
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(CMR_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     for (int qi = 0; qi < nq; ++qi) {
-        rc = scores_enqueue(idx, ws, (const float*)ws->d_q.p + (size_t)qi * idx->dim, 1, (float*)ws->d_out.p, n);
-        if (rc) { (void)hipStreamSynchronize(s); return rc; }
-        HIP_TRY(cmr_launch_sort_scores((const float*)ws->d_out.p, n, kernel_id_base(idx), ws->d_cand.p, (int64_t*)ws->d_ids.p,
-                                       (float*)ws->d_scores.p, s));
-        { int rc_ = remap_ids_enqueue(idx, (int64_t*)ws->d_ids.p, n, s); if (rc_) { (void)hipStreamSynchronize(s); return rc_; } }
-        HIP_TRY(hipMemcpyAsync(out_ids + (size_t)qi * n, ws->d_ids.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(out_scores + (size_t)qi * n, ws->d_scores.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));     // staging buffers are reused by the next query
         if (out_max) out_max[qi] = out_scores[(size_t)qi * n];
         if (out_min) out_min[qi] = out_scores[(size_t)qi * n + n - 1];
     }

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/comorag_hip.h"
@@ -59,6 +60,7 @@ struct cmr_graph {
     std::mutex mu;                     // guards the pool and the passage-vertex map's replacement
     std::vector<PprScratch*> pool;
     int users = 0;                     // calls in flight (cmr_graph_set_passage_vertices waits for none)
+    int no_small = 0;                  // cmr_graph_set_option("no_small", 1): small graphs also take the multi-launch chain (tests hold the two against each other)
     std::condition_variable idle;
 };
 
@@ -169,6 +171,91 @@ __global__ __launch_bounds__(PPR_T) void ppr_gather_kernel(const double* __restr
     if (i < n) out[i] = x[vertex_of_row[i]];
 }
 
+// ------------------------------------------------------------------------------------------ small graphs: ONE launch
+// ComoRAG's graphs are small (a few thousand passages and entities): the chain above is then ~95 launches of a few
+// microseconds each, all latency.  Up to PPR_SMALL_NV vertices ONE workgroup does everything after the scan: min / max of
+// the raw scores, the scatter into the reset vector, the phrase seeds, cleaning + normalisation, every power-iteration step
+// (x and y live in LDS, one __syncthreads per step instead of two launches) and the gather of the passage vertices.
+// Same arithmetic as the chain, fp64 throughout; the summation order of the three reductions (reset sum, dangling mass)
+// is this kernel's own fixed order (thread-strided partials, wave shuffles, waves in order), so results are reproducible
+// bit for bit per path and agree with the chain to rounding (tests: 1e-10 against the oracle on both).
+#define PPR_SMALL_T 1024
+#define PPR_SMALL_NV 8192          // x, y as doubles in LDS: 16 B per vertex of the 160 KiB
+__device__ __forceinline__ double small_block_sum(double v, double* sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();                                   // sh may still be read from the previous reduction
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < PPR_SMALL_T / 64; ++w) t += sh[w];      // fixed order
+    return t;
+}
+__global__ __launch_bounds__(PPR_SMALL_T) void ppr_small_kernel(const long long* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ wnorm,
+                                                                const int* __restrict__ dangling, int nd, int nv,
+                                                                const float* __restrict__ scores, int n, const int* __restrict__ vertex_of_row, double pnw,
+                                                                const int* __restrict__ seed_v, const double* __restrict__ seed_w, int ns,
+                                                                double* __restrict__ reset, double d, int iters, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ppr_smem[];
+    __shared__ double sh[PPR_SMALL_T / 64];
+    __shared__ float shf[2 * (PPR_SMALL_T / 64)];
+    double* x = reinterpret_cast<double*>(ppr_smem);
+    double* y = x + nv;
+    const int tid = threadIdx.x;
+    if (scores) {          // fused entry: reset <- min_max(scores) * pnw at the passage vertices (+ seeds); else reset holds the caller's vector
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        for (int i = tid; i < n; i += PPR_SMALL_T) { const float v = scores[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if ((tid & 63) == 0) { shf[tid >> 6] = mn; shf[PPR_SMALL_T / 64 + (tid >> 6)] = mx; }
+        for (int i = tid; i < nv; i += PPR_SMALL_T) reset[i] = 0.0;
+        __syncthreads();
+        mn = shf[0]; mx = shf[PPR_SMALL_T / 64];
+        for (int w = 1; w < PPR_SMALL_T / 64; ++w) { mn = fminf(mn, shf[w]); mx = fmaxf(mx, shf[PPR_SMALL_T / 64 + w]); }
+        const float range = mx - mn;
+        for (int i = tid; i < n; i += PPR_SMALL_T) {
+            const float norm = range == 0.0f ? 1.0f : (scores[i] - mn) / range;          // utils/misc_utils.py:141-150, fp32
+            reset[vertex_of_row[i]] = (double)norm * pnw;
+        }
+        __syncthreads();
+        for (int i = tid; i < ns; i += PPR_SMALL_T) reset[seed_v[i]] += seed_w[i];        // distinct vertices (merge_seeds)
+        __syncthreads();
+    }
+    double acc = 0.0;
+    for (int i = tid; i < nv; i += PPR_SMALL_T) {
+        double v = reset[i];
+        if (!(v >= 0.0)) v = 0.0;                       // ComoRAG.py:1090
+        reset[i] = v;
+        acc += v;
+    }
+    const double tot = small_block_sum(acc, sh);
+    for (int i = tid; i < nv; i += PPR_SMALL_T) {
+        const double v = tot > 0.0 ? reset[i] / tot : 1.0 / (double)nv;
+        reset[i] = v;
+        x[i] = v;
+    }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        double D = 0.0;
+        if (nd) {
+            double a = 0.0;
+            for (int i = tid; i < nd; i += PPR_SMALL_T) a += x[dangling[i]];
+            D = small_block_sum(a, sh);
+        }
+        for (int i = tid; i < nv; i += PPR_SMALL_T) {
+            double a = 0.0;
+            for (long long e = rowptr[i]; e < rowptr[i + 1]; ++e) a += wnorm[e] * x[col[e]];
+            const double r = reset[i];
+            y[i] = d * (a + D * r) + (1.0 - d) * r;
+        }
+        __syncthreads();
+        double* t = x; x = y; y = t;
+    }
+    if (scores) { for (int i = tid; i < n; i += PPR_SMALL_T) out[i] = x[vertex_of_row[i]]; }
+    else { for (int i = tid; i < nv; i += PPR_SMALL_T) out[i] = x[i]; }
+}
+
 static unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + PPR_T - 1) / PPR_T); }
 
 // One set of per-call vectors out of the graph's pool (allocated on first use, one per concurrent caller).
@@ -214,14 +301,32 @@ struct ScratchGuard {
     ~ScratchGuard() { if (sc) scratch_release(g, sc); }
 };
 
+static int ppr_iters(double damping, double tol, int max_iter) {
+    int iters = (int)std::ceil(std::log(std::max(tol, 1e-300) / 2.0) / std::log(std::min(std::max(damping, 1e-12), 1.0 - 1e-12)));
+    iters = std::max(1, std::min(iters, max_iter > 0 ? max_iter : 1000));
+    if (damping <= 0.0) iters = 1;
+    return iters;
+}
+
+// everything after the scan in one launch (graphs of <= PPR_SMALL_NV vertices).  scores == nullptr: sc->reset already holds
+// the caller's reset vector and `out` receives all nv scores; else out receives the n passage scores.
+static int ppr_small(cmr_graph* g, PprScratch* sc, const float* scores, long long n, double pnw, int ns, double damping, double tol, int max_iter,
+                     hipStream_t s, int* iters_out, double* out) {
+    const int iters = ppr_iters(damping, tol, max_iter);
+    PPR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppr_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PPR_SMALL_NV * 16));
+    hipLaunchKernelGGL(ppr_small_kernel, dim3(1), dim3(PPR_SMALL_T), (size_t)g->nv * 16, s, g->rowptr, g->col, g->wnorm, g->dangling, (int)g->n_dangling, (int)g->nv,
+                       scores, (int)n, g->vertex_of_row, pnw, sc->seed_v, sc->seed_w, ns, sc->reset, damping, iters, out);
+    PPR_TRY(hipGetLastError());
+    if (iters_out) *iters_out = iters;
+    return CMR_OK;
+}
+
 // reset (device, raw) -> normalised -> power iteration -> *result holds the stationary vector (sc->x or sc->y)
 static int ppr_iterate(cmr_graph* g, PprScratch* sc, double damping, double tol, int max_iter, hipStream_t s, int* iters_out, double** result) {
     const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(g->nv));
     hipLaunchKernelGGL(ppr_clean_sum_kernel, dim3(nparts), dim3(PPR_T), 0, s, sc->reset, g->nv, sc->red);
     hipLaunchKernelGGL(ppr_normalise_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, sc->reset, sc->x, g->nv, sc->red, nparts);
-    int iters = (int)std::ceil(std::log(std::max(tol, 1e-300) / 2.0) / std::log(std::min(std::max(damping, 1e-12), 1.0 - 1e-12)));
-    iters = std::max(1, std::min(iters, max_iter > 0 ? max_iter : 1000));
-    if (damping <= 0.0) iters = 1;
+    const int iters = ppr_iters(damping, tol, max_iter);
     double *x = sc->x, *y = sc->y;
     for (int it = 0; it < iters; ++it) {
         if (g->n_dangling) hipLaunchKernelGGL(ppr_dangling_kernel, dim3(1), dim3(PPR_T), 0, s, x, g->dangling, g->n_dangling, sc->red + PPR_RED_BLOCKS);
@@ -344,6 +449,12 @@ int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_
     return CMR_OK;
 }
 
+int32_t cmr_graph_set_option(cmr_graph_t* g, const char* name, int64_t value) {
+    if (!g || !name) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
+    if (std::string(name) == "no_small") { g->no_small = (int)value; return CMR_OK; }
+    return cmr_fail(CMR_ERR_INVALID, "unknown graph option '%s'", name);
+}
+
 int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, double tol, int32_t max_iter, double* out_scores, int32_t* iters) {
     if (!g || !reset || !out_scores) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
     PPR_TRY(hipSetDevice(g->device));
@@ -355,8 +466,14 @@ int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, doubl
     auto body = [&]() -> int {
         PPR_TRY(hipMemcpyAsync(sc->reset, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, s));
         double* res = nullptr;
-        int rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
-        if (rc_) return rc_;
+        if (g->nv <= PPR_SMALL_NV && !g->no_small) {          // one launch; the result lands in sc->y (free: x / y live in LDS there)
+            int rc_ = ppr_small(g, sc, nullptr, 0, 0.0, 0, damping, tol, max_iter, s, iters, sc->y);
+            if (rc_) return rc_;
+            res = sc->y;
+        } else {
+            int rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
+            if (rc_) return rc_;
+        }
         PPR_TRY(hipMemcpyAsync(out_scores, res, (size_t)g->nv * 8, hipMemcpyDeviceToHost, s));
         return CMR_OK;
     };
@@ -394,6 +511,12 @@ int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, cons
         if (ns) {
             PPR_TRY(hipMemcpyAsync(sc->seed_v, sv.data(), (size_t)ns * 4, hipMemcpyHostToDevice, s));
             PPR_TRY(hipMemcpyAsync(sc->seed_w, sw.data(), (size_t)ns * 8, hipMemcpyHostToDevice, s));
+        }
+        if (g->nv <= PPR_SMALL_NV && !g->no_small) {          // ComoRAG-sized graph: one launch behind the scan
+            rc_ = ppr_small(g, sc, scores, n, passage_node_weight, ns, damping, tol, max_iter, s, iters, sc->out);
+            if (rc_) return rc_;
+            PPR_TRY(hipMemcpyAsync(out_doc_scores, sc->out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+            return CMR_OK;
         }
         PPR_TRY(hipMemsetAsync(sc->reset, 0, (size_t)g->nv * 8, s));
         const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(n));

@@ -635,8 +635,13 @@ __device__ __forceinline__ u64 wide_push_sparse(const f32x16& acc, const float (
 template <int BASE>
 __device__ __forceinline__ void wide_wait_group(int x) {
     static_assert(BASE + 32 <= 63, "vmcnt is a 6-bit counter");
-    if (x == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
-    else if (x == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 1) : "memory");
+    // x == 0 (no slow-path store since the pieces were issued) is the case of nearly every group: ONE compare and an
+    // untaken branch in front of its wait.  Left as a plain if / else-if chain hipcc lowers all seven cases into one
+    // binary search tree — a dozen SALU instructions and a taken branch on the common path, at the one point of a group
+    // where the matrix pipe is about to run dry (the opaque copy keeps the x == 0 test out of that tree).
+    if (__builtin_expect(x == 0, 1)) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory"); return; }
+    asm volatile("" : "+s"(x));
+    if (x == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 1) : "memory");
     else if (x < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 2) : "memory");
     else if (x < 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 4) : "memory");
     else if (x < 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + 8) : "memory");

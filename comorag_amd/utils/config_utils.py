@@ -31,6 +31,7 @@ class BaseConfig:
     embedding_cache_path: Optional[str] = None
     embedding_length_bucketing: bool = True       # group a batch_encode call's prompts into mini-batches of similar token count
     embedding_tokenizer_threads: int = 2          # host threads tokenising ahead of the forward
+    embedding_bucket_window: int = 4              # length bucketing sorts within windows of this many batches (the next windows are tokenised meanwhile)
     embedding_tokenizer_processes: int = 0        # > 0: tokenise in that many worker PROCESSES instead (the Rust tokenizer holds the GIL)
 
 

@@ -231,6 +231,13 @@ def test_encoder_end_to_end_vs_oracle():
     em2 = cls(global_config=cfg2, embedding_model_name=cfg2.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
     assert em._bucket and not em2._bucket
     np.testing.assert_allclose(em2.batch_encode(texts), got, atol=2e-5)
+    # bucketing within windows of ONE reference chunk (three windows here, the next ones tokenised while one is on the GPU),
+    # and the same with the tokenizer in worker processes: same rows, same order
+    for extra in ({"embedding_bucket_window": 1}, {"embedding_bucket_window": 2, "embedding_tokenizer_processes": 2}):
+        cfg3 = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=4, embedding_max_seq_len=2048, **extra)
+        em3 = cls(global_config=cfg3, embedding_model_name=cfg3.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+        np.testing.assert_allclose(em3.batch_encode(texts), got, atol=2e-5)
+        em3.close()
 
 
 def test_store_insert_appends_the_encoder_device_tensor(tmp_path):
