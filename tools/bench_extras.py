@@ -41,11 +41,11 @@ def _median_us(fn, reps, warm=3):
 def config4_probe_loop(torch, device, dim=768, dtype="bf16", rows0=2_000_000, k=20, cycles=5, probes=8, cpu_nodes=20_000):
     """BASELINE config 4: 5 reasoning cycles x (ONE B = 8 search over the 2 M-chunk memory pool, k = 20, then an append of
     25 rows [3 nodes x 8 probes + 1 fusion]); afterwards one 65 536-row burst that forces a capacity doubling.  The index is
-    created WITHOUT a capacity hint beyond the initial rows, so the growth path (hipMemcpyAsync into a 2x allocation) is
-    what the burst times.  Every appended row is searched for right after its append: it must come back first with its
+    created with room for the cycles' small appends only, so the growth path (hipMemcpyAsync into a 2x allocation) is what
+    the burst times.  Every appended row is searched for right after its append: it must come back first with its
     append-order id."""
     from comorag_amd.index import DenseIndex
-    idx = DenseIndex(dim, dtype, device=device.index or 0, capacity_hint=rows0)
+    idx = DenseIndex(dim, dtype, device=device.index or 0, capacity_hint=rows0 + 4096)     # room for the cycles' 25-row appends, not for the burst
     for blk in _unit_rows_dev(torch, rows0, dim, device, 4001):
         idx.append_dev(blk)
     torch.cuda.synchronize(device)
