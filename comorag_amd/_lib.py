@@ -67,7 +67,6 @@ SIGNATURES = {
     "cmr_graph_destroy": (_i32, [_p]),
     "cmr_graph_set_passage_vertices": (_i32, [_p, _p, _i64]),
     "cmr_graph_ppr": (_i32, [_p, _p, _f64, _f64, _i32, _p, _P(_i32)]),
-    "cmr_graph_set_option": (_i32, [_p, C.c_char_p, _i64]),
     "cmr_index_ppr": (_i32, [_p, _p, _p, _p, _p, _i32, _f64, _f64, _f64, _i32, _p, _P(_i32)]),
     "cmr_pack_candidates_dev": (_i32, [_p, _p, _i64, _p, _p]),
     "cmr_merge_keys_dev": (_i32, [_p, _i32, _i32, _i32, _p, _p, _p]),

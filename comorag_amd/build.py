@@ -155,7 +155,7 @@ def audit_wide(asm_text: str) -> dict:
         # loop).  Anything beyond that means query fragments are being shuttled between the register files in front of
         # the MFMAs.
         n_read = sum(c.startswith("v_accvgpr_read") for c in code)
-        lim_read = 64 * 3 if nt == 2 else 48
+        lim_read = 64 * 3 if nt == 2 else (64 if nw == 8 else 48)      # 8-wave kernel: asm fold + cold partial fold + two pushes that re-read
         if n_read > lim_read:
             problems.append(f"{n_read} v_accvgpr_read > {lim_read}")
         n_mfma = 0

@@ -14,13 +14,16 @@
 // prpack solves this system directly to ~1e-10; a power iteration contracts by d per step, so ceil(log(tol/2)/log(d))
 // steps reach tol in the 1-norm (43 steps for tol = 1e-12 at d = 0.5).  fp64 throughout, fixed summation order
 // (pull-style CSR rows, block-ordered reductions): results are reproducible bit for bit.
+// (Round 3 built and measured a single-launch variant for ComoRAG-sized graphs — one workgroup, x / y in LDS, a thread's
+// rows advanced together: 1064 us per query at 5 K passages / 1.5 K entities against 551 us for this chain of ~50 launches;
+// one CU's L2-latency-bound row walks lose against 43 grid-wide steps.  Dropped.  gpurun_out of the round: profiles/r3_measurements.md.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
-#include <string>
 #include <vector>
 
 #include "../../include/comorag_hip.h"
@@ -38,7 +41,16 @@ struct PprScratch {
     int* seed_v = nullptr;
     double* seed_w = nullptr;
     long long seed_cap = 0, out_cap = 0;
+    // the power iteration of THIS scratch as an instantiated hipGraph (clean + normalise + `iters` steps: every argument is
+    // one of this scratch's pointers or a graph constant), keyed by (damping, iters); replayed with one hipGraphLaunch
+    hipGraphExec_t iter_exec = nullptr;
+    double iter_damping = 0.0;
+    int iter_count = 0;
+    double* iter_result = nullptr;
+    hipStream_t own = nullptr;         // cmr_graph_ppr's stream (capturable, unlike the legacy default stream)
     void release() {
+        if (iter_exec) (void)hipGraphExecDestroy(iter_exec);
+        if (own) (void)hipStreamDestroy(own);
         for (void* p : {(void*)reset, (void*)x, (void*)y, (void*)red, (void*)out, (void*)mm, (void*)seed_v, (void*)seed_w})
             if (p) (void)hipFree(p);
     }
@@ -60,7 +72,7 @@ struct cmr_graph {
     std::mutex mu;                     // guards the pool and the passage-vertex map's replacement
     std::vector<PprScratch*> pool;
     int users = 0;                     // calls in flight (cmr_graph_set_passage_vertices waits for none)
-    int no_small = 0;                  // cmr_graph_set_option("no_small", 1): small graphs also take the multi-launch chain (tests hold the two against each other)
+    std::atomic<bool> use_graph{true}; // power iteration replayed as a captured hipGraph (cleared if capture ever fails)
     std::condition_variable idle;
 };
 
@@ -154,138 +166,35 @@ __global__ __launch_bounds__(PPR_T) void ppr_dangling_kernel(const double* __res
     if (threadIdx.x == 0) out[0] = t;
 }
 
-// y_i = d * (sum_{j in N(i)} wnorm_ij * x_j + D * r_i) + (1 - d) * r_i      (one thread per vertex: graph rows are short)
+// y_i = d * (sum_{j in N(i)} wnorm_ij * x_j + D * r_i) + (1 - d) * r_i
+// PPR_LPR lanes per vertex: ComoRAG's graphs mix passage vertices of degree ~3 with entity vertices of degree 10-30 and
+// more; with one thread per vertex a step lasted as long as the LONGEST row's chain of dependent loads (col -> x[col]):
+// 10 us per step at 6500 vertices, 197 us at 1.2 M (0.4 TB/s).  Eight lanes stride over a row's entries (coalesced col /
+// wnorm reads), each lane sums its entries in ascending order, the eight partials are combined by a fixed xor tree: one
+// summation order per row, reproducible bit for bit.
+#define PPR_LPR 8
 __global__ __launch_bounds__(PPR_T) void ppr_step_kernel(const long long* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ wnorm,
                                                          const double* __restrict__ x, const double* __restrict__ r, const double* __restrict__ dmass,
                                                          double d, long long nv, double* __restrict__ y) {
-    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
-    if (i >= nv) return;
+    const long long gt = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    const long long i = gt / PPR_LPR;
+    const int sub = (int)(gt % PPR_LPR);
     double acc = 0.0;
-    for (long long e = rowptr[i]; e < rowptr[i + 1]; ++e) acc += wnorm[e] * x[col[e]];
-    const double D = dmass ? dmass[0] : 0.0;
-    y[i] = d * (acc + D * r[i]) + (1.0 - d) * r[i];
+    if (i < nv) {
+        const long long e1 = rowptr[i + 1];
+        for (long long e = rowptr[i] + sub; e < e1; e += PPR_LPR) acc += wnorm[e] * x[col[e]];
+    }
+#pragma unroll
+    for (int off = PPR_LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (i < nv && sub == 0) {
+        const double D = dmass ? dmass[0] : 0.0;
+        y[i] = d * (acc + D * r[i]) + (1.0 - d) * r[i];
+    }
 }
 
 __global__ __launch_bounds__(PPR_T) void ppr_gather_kernel(const double* __restrict__ x, const int* __restrict__ vertex_of_row, long long n, double* __restrict__ out) {
     const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
     if (i < n) out[i] = x[vertex_of_row[i]];
-}
-
-// ------------------------------------------------------------------------------------------ small graphs: ONE launch
-// ComoRAG's graphs are small (a few thousand passages and entities): the chain above is then ~95 launches of a few
-// microseconds each, all latency.  Up to PPR_SMALL_NV vertices ONE workgroup does everything after the scan: min / max of
-// the raw scores, the scatter into the reset vector, the phrase seeds, cleaning + normalisation, every power-iteration step
-// (x and y live in LDS, one __syncthreads per step instead of two launches) and the gather of the passage vertices.
-// Same arithmetic as the chain, fp64 throughout; the summation order of the three reductions (reset sum, dangling mass)
-// is this kernel's own fixed order (thread-strided partials, wave shuffles, waves in order), so results are reproducible
-// bit for bit per path and agree with the chain to rounding (tests: 1e-10 against the oracle on both).
-#define PPR_SMALL_T 1024
-#define PPR_SMALL_NV 8192          // x, y as doubles in LDS: 16 B per vertex of the 160 KiB
-__device__ __forceinline__ double small_block_sum(double v, double* sh) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();                                   // sh may still be read from the previous reduction
-    if (lane == 0) sh[wave] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int w = 0; w < PPR_SMALL_T / 64; ++w) t += sh[w];      // fixed order
-    return t;
-}
-__global__ __launch_bounds__(PPR_SMALL_T) void ppr_small_kernel(const long long* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ wnorm,
-                                                                const int* __restrict__ dangling, int nd, int nv,
-                                                                const float* __restrict__ scores, int n, const int* __restrict__ vertex_of_row, double pnw,
-                                                                const int* __restrict__ seed_v, const double* __restrict__ seed_w, int ns,
-                                                                double* __restrict__ reset, double d, int iters, double* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ppr_smem[];
-    __shared__ double sh[PPR_SMALL_T / 64];
-    __shared__ float shf[2 * (PPR_SMALL_T / 64)];
-    double* x = reinterpret_cast<double*>(ppr_smem);
-    double* y = x + nv;
-    const int tid = threadIdx.x;
-    if (scores) {          // fused entry: reset <- min_max(scores) * pnw at the passage vertices (+ seeds); else reset holds the caller's vector
-        float mn = __builtin_inff(), mx = -__builtin_inff();
-        for (int i = tid; i < n; i += PPR_SMALL_T) { const float v = scores[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
-        if ((tid & 63) == 0) { shf[tid >> 6] = mn; shf[PPR_SMALL_T / 64 + (tid >> 6)] = mx; }
-        for (int i = tid; i < nv; i += PPR_SMALL_T) reset[i] = 0.0;
-        __syncthreads();
-        mn = shf[0]; mx = shf[PPR_SMALL_T / 64];
-        for (int w = 1; w < PPR_SMALL_T / 64; ++w) { mn = fminf(mn, shf[w]); mx = fmaxf(mx, shf[PPR_SMALL_T / 64 + w]); }
-        const float range = mx - mn;
-        for (int i = tid; i < n; i += PPR_SMALL_T) {
-            const float norm = range == 0.0f ? 1.0f : (scores[i] - mn) / range;          // utils/misc_utils.py:141-150, fp32
-            reset[vertex_of_row[i]] = (double)norm * pnw;
-        }
-        __syncthreads();
-        for (int i = tid; i < ns; i += PPR_SMALL_T) reset[seed_v[i]] += seed_w[i];        // distinct vertices (merge_seeds)
-        __syncthreads();
-    }
-    double acc = 0.0;
-    for (int i = tid; i < nv; i += PPR_SMALL_T) {
-        double v = reset[i];
-        if (!(v >= 0.0)) v = 0.0;                       // ComoRAG.py:1090
-        reset[i] = v;
-        acc += v;
-    }
-    const double tot = small_block_sum(acc, sh);
-    for (int i = tid; i < nv; i += PPR_SMALL_T) {
-        const double v = tot > 0.0 ? reset[i] / tot : 1.0 / (double)nv;
-        reset[i] = v;
-        x[i] = v;
-    }
-    __syncthreads();
-    // A thread owns up to 8 vertices (tid + 1024 v).  Walking one vertex's row after the other is a chain of dependent L2
-    // loads (col -> x[col]) per entry — 20 us per step at 6500 vertices, slower than the multi-launch chain.  Instead the
-    // thread advances ALL its rows together, entry slot by entry slot: 8 independent (col, wnorm) load pairs in flight per
-    // slot, and the trip count is the longest of its rows instead of their sum.  Each row is still summed in ascending
-    // entry order (the chain's order: the per-vertex sums are bit-identical).
-    constexpr int VPT = PPR_SMALL_NV / PPR_SMALL_T;
-    int st[VPT], len[VPT];
-    double rv[VPT];
-    int maxlen = 0;
-#pragma unroll
-    for (int v = 0; v < VPT; ++v) {
-        const int i = tid + PPR_SMALL_T * v;
-        st[v] = i < nv ? (int)rowptr[i] : 0;
-        len[v] = i < nv ? (int)(rowptr[i + 1] - rowptr[i]) : 0;
-        rv[v] = i < nv ? reset[i] : 0.0;
-        maxlen = len[v] > maxlen ? len[v] : maxlen;
-    }
-    for (int it = 0; it < iters; ++it) {
-        double D = 0.0;
-        if (nd) {
-            double a = 0.0;
-            for (int i = tid; i < nd; i += PPR_SMALL_T) a += x[dangling[i]];
-            D = small_block_sum(a, sh);
-        }
-        double a[VPT];
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) a[v] = 0.0;
-        for (int j = 0; j < maxlen; ++j) {
-            int c[VPT];
-            double w[VPT];
-#pragma unroll
-            for (int v = 0; v < VPT; ++v) {
-                const bool on = j < len[v];
-                c[v] = on ? col[st[v] + j] : 0;
-                w[v] = on ? wnorm[st[v] + j] : 0.0;
-            }
-#pragma unroll
-            for (int v = 0; v < VPT; ++v)
-                if (j < len[v]) a[v] += w[v] * x[c[v]];
-        }
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int i = tid + PPR_SMALL_T * v;
-            if (i < nv) y[i] = d * (a[v] + D * rv[v]) + (1.0 - d) * rv[v];
-        }
-        __syncthreads();
-        double* t = x; x = y; y = t;
-    }
-    if (scores) { for (int i = tid; i < n; i += PPR_SMALL_T) out[i] = x[vertex_of_row[i]]; }
-    else { for (int i = tid; i < nv; i += PPR_SMALL_T) out[i] = x[i]; }
 }
 
 static unsigned blocks_for(long long n) { return (unsigned)std::max<long long>(1, (n + PPR_T - 1) / PPR_T); }
@@ -340,34 +249,52 @@ static int ppr_iters(double damping, double tol, int max_iter) {
     return iters;
 }
 
-// everything after the scan in one launch (graphs of <= PPR_SMALL_NV vertices).  scores == nullptr: sc->reset already holds
-// the caller's reset vector and `out` receives all nv scores; else out receives the n passage scores.
-static int ppr_small(cmr_graph* g, PprScratch* sc, const float* scores, long long n, double pnw, int ns, double damping, double tol, int max_iter,
-                     hipStream_t s, int* iters_out, double* out) {
-    const int iters = ppr_iters(damping, tol, max_iter);
-    PPR_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(ppr_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PPR_SMALL_NV * 16));
-    hipLaunchKernelGGL(ppr_small_kernel, dim3(1), dim3(PPR_SMALL_T), (size_t)g->nv * 16, s, g->rowptr, g->col, g->wnorm, g->dangling, (int)g->n_dangling, (int)g->nv,
-                       scores, (int)n, g->vertex_of_row, pnw, sc->seed_v, sc->seed_w, ns, sc->reset, damping, iters, out);
-    PPR_TRY(hipGetLastError());
-    if (iters_out) *iters_out = iters;
-    return CMR_OK;
-}
-
 // reset (device, raw) -> normalised -> power iteration -> *result holds the stationary vector (sc->x or sc->y)
-static int ppr_iterate(cmr_graph* g, PprScratch* sc, double damping, double tol, int max_iter, hipStream_t s, int* iters_out, double** result) {
+static void ppr_iterate_launches(cmr_graph* g, PprScratch* sc, double damping, int iters, hipStream_t s, double** result) {
     const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(g->nv));
     hipLaunchKernelGGL(ppr_clean_sum_kernel, dim3(nparts), dim3(PPR_T), 0, s, sc->reset, g->nv, sc->red);
     hipLaunchKernelGGL(ppr_normalise_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, sc->reset, sc->x, g->nv, sc->red, nparts);
-    const int iters = ppr_iters(damping, tol, max_iter);
     double *x = sc->x, *y = sc->y;
     for (int it = 0; it < iters; ++it) {
         if (g->n_dangling) hipLaunchKernelGGL(ppr_dangling_kernel, dim3(1), dim3(PPR_T), 0, s, x, g->dangling, g->n_dangling, sc->red + PPR_RED_BLOCKS);
-        hipLaunchKernelGGL(ppr_step_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, x, sc->reset,
+        hipLaunchKernelGGL(ppr_step_kernel, dim3(blocks_for(g->nv * PPR_LPR)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, x, sc->reset,
                            g->n_dangling ? sc->red + PPR_RED_BLOCKS : nullptr, damping, g->nv, y);
         std::swap(x, y);
     }
     *result = x;
+}
+
+// The iteration is ~45-90 dependent launches of a few microseconds each: launch-bound.  They are captured ONCE per scratch
+// into a hipGraph (every argument is a pointer of this scratch, the graph's CSR arrays or a constant) and replayed with a
+// single hipGraphLaunch per query; any other (damping, iteration count) re-captures.  If capture or instantiation fails the
+// plain launches run — same kernels, same order, same results.
+static int ppr_iterate(cmr_graph* g, PprScratch* sc, double damping, double tol, int max_iter, hipStream_t s, int* iters_out, double** result) {
+    const int iters = ppr_iters(damping, tol, max_iter);
     if (iters_out) *iters_out = iters;
+    if (g->use_graph && (!sc->iter_exec || sc->iter_damping != damping || sc->iter_count != iters)) {
+        if (sc->iter_exec) { (void)hipGraphExecDestroy(sc->iter_exec); sc->iter_exec = nullptr; }
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            double* res = nullptr;
+            ppr_iterate_launches(g, sc, damping, iters, s, &res);
+            if (hipStreamEndCapture(s, &graph) == hipSuccess && graph) {
+                if (hipGraphInstantiate(&sc->iter_exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    sc->iter_damping = damping; sc->iter_count = iters; sc->iter_result = res;
+                } else {
+                    sc->iter_exec = nullptr;
+                }
+                (void)hipGraphDestroy(graph);
+            }
+        }
+        (void)hipGetLastError();                 // a failed capture must not poison the plain path below
+        if (!sc->iter_exec) g->use_graph = false;
+    }
+    if (g->use_graph && sc->iter_exec) {
+        PPR_TRY(hipGraphLaunch(sc->iter_exec, s));
+        *result = sc->iter_result;
+        return CMR_OK;
+    }
+    ppr_iterate_launches(g, sc, damping, iters, s, result);
     PPR_TRY(hipGetLastError());
     return CMR_OK;
 }
@@ -481,12 +408,6 @@ int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_
     return CMR_OK;
 }
 
-int32_t cmr_graph_set_option(cmr_graph_t* g, const char* name, int64_t value) {
-    if (!g || !name) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
-    if (std::string(name) == "no_small") { g->no_small = (int)value; return CMR_OK; }
-    return cmr_fail(CMR_ERR_INVALID, "unknown graph option '%s'", name);
-}
-
 int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, double tol, int32_t max_iter, double* out_scores, int32_t* iters) {
     if (!g || !reset || !out_scores) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
     PPR_TRY(hipSetDevice(g->device));
@@ -494,18 +415,13 @@ int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, doubl
     int rc = scratch_acquire(g, &sc);
     if (rc) return rc;
     ScratchGuard guard{g, sc};
-    hipStream_t s = hipStreamPerThread;                     // concurrent callers do not queue behind each other on the null stream
+    if (!sc->own) PPR_TRY(hipStreamCreateWithFlags(&sc->own, hipStreamNonBlocking));
+    hipStream_t s = sc->own;                                // concurrent callers do not queue behind each other on the null stream
     auto body = [&]() -> int {
         PPR_TRY(hipMemcpyAsync(sc->reset, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, s));
         double* res = nullptr;
-        if (g->nv <= PPR_SMALL_NV && !g->no_small) {          // one launch; the result lands in sc->y (free: x / y live in LDS there)
-            int rc_ = ppr_small(g, sc, nullptr, 0, 0.0, 0, damping, tol, max_iter, s, iters, sc->y);
-            if (rc_) return rc_;
-            res = sc->y;
-        } else {
-            int rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
-            if (rc_) return rc_;
-        }
+        int rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
+        if (rc_) return rc_;
         PPR_TRY(hipMemcpyAsync(out_scores, res, (size_t)g->nv * 8, hipMemcpyDeviceToHost, s));
         return CMR_OK;
     };
@@ -543,12 +459,6 @@ int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, cons
         if (ns) {
             PPR_TRY(hipMemcpyAsync(sc->seed_v, sv.data(), (size_t)ns * 4, hipMemcpyHostToDevice, s));
             PPR_TRY(hipMemcpyAsync(sc->seed_w, sw.data(), (size_t)ns * 8, hipMemcpyHostToDevice, s));
-        }
-        if (g->nv <= PPR_SMALL_NV && !g->no_small) {          // ComoRAG-sized graph: one launch behind the scan
-            rc_ = ppr_small(g, sc, scores, n, passage_node_weight, ns, damping, tol, max_iter, s, iters, sc->out);
-            if (rc_) return rc_;
-            PPR_TRY(hipMemcpyAsync(out_doc_scores, sc->out, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-            return CMR_OK;
         }
         PPR_TRY(hipMemsetAsync(sc->reset, 0, (size_t)g->nv * 8, s));
         const int nparts = (int)std::min<long long>(PPR_RED_BLOCKS, blocks_for(n));

@@ -521,10 +521,10 @@ __device__ __forceinline__ float wide_minmax_partial(const f32x16& acc, int nval
 // 8-wave kernel: k-steps of a tile whose B-operand is served from LDS instead of a register (the wave has 256 registers:
 // 192 of fragments + 16 accumulators + a 16-register read-ahead ring leave hipcc too few for everything else)
 #ifndef WIDE8_KLDS
-#define WIDE8_KLDS 4
+#define WIDE8_KLDS 8
 #endif
 #ifndef WIDE8_NST
-#define WIDE8_NST 6
+#define WIDE8_NST 5
 #endif
 #define WIDE8_STG 64
 #define WIDE_AMOVE 8      // NT = 2: k-steps of tile 0 whose B-operand lives in the AGPR half
@@ -695,6 +695,7 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
     constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = NW == 8 ? 4 : WIDE_ADEPTH;
     constexpr int STG = NW == 8 ? WIDE8_STG : WIDE_STG;         // staging records per wave (LDS budget)
     static_assert(NW == 4 || (NW == 8 && NT == 1), "8 waves hold one tile each");
+    static_assert(NW == 4 || (size_t)STG * 16 <= (size_t)(CAP + 2) * 8, "8-wave kernel: the staging records live in the compaction stage");
     static_assert(KS % GRP == 0 && GRP % NW == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && NST >= 4, "group geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -712,10 +713,12 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
     int* cnt_all = reinterpret_cast<int*>(smem + NST * GRP * 1024);                   // [NQB]
     u64* cstage_all = reinterpret_cast<u64*>(cnt_all + NQB);                          // [WAVES][CAP+2]
     v4u* qlds_all = reinterpret_cast<v4u*>(cstage_all + NW * (CAP + 2));             // [WAVES][NT][KLDS][64]
-    uint4* stg_all = reinterpret_cast<uint4*>(qlds_all + (size_t)NW * NT * KLDS * 64);   // [WAVES][STG] staging records
-    int* tail_all = reinterpret_cast<int*>(stg_all + (size_t)NW * STG);               // [WAVES]
+    // (8-wave kernel: the staging records of a push are dead once its cooperative stores were issued, and a compaction only
+    //  ever follows a push: the two per-wave scratch areas share their LDS — WIDE8_STG records = CAP + 2 keys at CAP = 128)
+    uint4* stg_all = NW == 8 ? reinterpret_cast<uint4*>(cstage_all) : reinterpret_cast<uint4*>(qlds_all + (size_t)NW * NT * KLDS * 64);   // [WAVES][STG] staging records
+    int* tail_all = reinterpret_cast<int*>(NW == 8 ? reinterpret_cast<unsigned char*>(qlds_all + (size_t)NW * NT * KLDS * 64) : reinterpret_cast<unsigned char*>(stg_all + (size_t)NW * STG));   // [WAVES]
     v4u* qlds = qlds_all + (size_t)wave * NT * KLDS * 64 + lane;
-    uint4* stg = stg_all + (size_t)wave * STG;
+    uint4* stg = NW == 8 ? reinterpret_cast<uint4*>(cstage_all + wave * (CAP + 2)) : stg_all + (size_t)wave * STG;
     int* stg_tail = tail_all + wave;
     int* cnt_w = cnt_all + wave * NT * 32;
     u64* cstage = cstage_all + wave * (CAP + 2);
@@ -1041,7 +1044,7 @@ static WideCfg wide_cfg(int ks, int cap, int waves) {
 size_t cmr_wide_lds_bytes(int ks, int cap, int waves) {
     const WideCfg c = wide_cfg(ks, cap, waves);
     return (size_t)c.nst * WIDE_GROUP * 1024 + (size_t)c.nw * c.nt * 32 * 4 + (size_t)c.nw * (cap + 2) * 8 + (size_t)c.nw * c.nt * c.klds * 1024 +
-           (size_t)c.nw * c.stg * 16 + c.nw * 4;
+           (c.nw == 8 ? 0 : (size_t)c.nw * c.stg * 16) + c.nw * 4;
 }
 
 // wide kernel availability: 16-bit dtypes at ks = 48 (768-d: 256 queries per pass — 4 waves x 2 tiles or 8 waves x 1 tile of 32),

@@ -44,10 +44,6 @@ class DeviceGraph:
             w = None
         return cls(graph.vcount(), src, dst, w, device=device)
 
-    def set_option(self, name: str, value: int) -> None:
-        """Route selector (cmr_graph_set_option): "no_small" = 1 takes the multi-launch chain also for small graphs."""
-        L.check(L.lib().cmr_graph_set_option(self._h, name.encode(), int(value)))
-
     def set_passage_vertices(self, passage_node_idxs: Sequence[int]) -> None:
         v = np.ascontiguousarray(passage_node_idxs, dtype=np.int32)
         L.check(L.lib().cmr_graph_set_passage_vertices(self._h, v.ctypes.data_as(C.c_void_p), len(v)))

@@ -220,10 +220,6 @@ int32_t cmr_graph_destroy(cmr_graph_t* g);
 int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_row, int64_t n_rows);
 int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, double tol, int32_t max_iter, double* out_scores,
                       int32_t* iters);
-/* Route selector, as cmr_index_set_option: "no_small" = 1 sends graphs of <= 8192 vertices (ComoRAG's own size: everything
- * after the scan is ONE launch there, x / y in LDS) through the multi-launch chain of the large graphs too.  Same results to
- * rounding (the reductions have each path's own fixed summation order).                                                   */
-int32_t cmr_graph_set_option(cmr_graph_t* g, const char* name, int64_t value);
 int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, const int32_t* seed_vertices,
                       const double* seed_weights, int32_t n_seeds, double passage_node_weight, double damping, double tol,
                       int32_t max_iter, double* out_doc_scores, int32_t* iters);
