@@ -52,6 +52,7 @@ SIGNATURES = {
     "cmr_index_set_id_base": (_i32, [_p, _i64]),
     "cmr_index_set_id_blocks": (_i32, [_p, _i32, _p, _p]),
     "cmr_index_set_option": (_i32, [_p, C.c_char_p, _i64]),
+    "cmr_index_get_option": (_i32, [_p, C.c_char_p, _P(_i64)]),
     "cmr_index_pipeline_stream": (_i32, [_p, _i32, _P(_p)]),
     "cmr_index_query_status": (_i32, [_p, _P(_i32)]),
     "cmr_stream_wait_event": (_i32, [_p, _p]),

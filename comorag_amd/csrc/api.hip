@@ -116,7 +116,10 @@ constexpr size_t kZeroCopyMax = 256 * 1024;   // synchronous host API: queries /
 
 struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullptr, main_done = nullptr; bool used = false; };
 #define CMR_PIPE_SLOTS 4
-struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sq = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; };
+// sp / sm / sm2: pre-phase and main scans of batches of <= 64 queries (with CU masks: sm, sm2 on n_cu - 64 CUs, sp on the other
+// 64); wp / wm: the same for wide batches (no masks: the wide kernel is matrix-pipe-bound and wants every CU); sq: candidate
+// merges and whatever the caller appends behind a batch (no mask: its small workgroups fit beside a scan workgroup on any CU)
+struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sm2 = nullptr, wp = nullptr, wm = nullptr, sq = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; unsigned nscan = 0; int scan_cus = 0; };
 
 }  // namespace
 
@@ -158,8 +161,13 @@ struct cmr_index {
     int no_small = 0;        // scan_no_small = 1: corpora of 1025 rows .. 64 K rows take the general path also for few queries
     int zero_copy = 1;       // zero_copy = 0: the synchronous host API copies queries / results instead of mapping them
     int wide_waves = 0;      // wide_waves = 4 | 8: waves per workgroup of the wide kernel at 768-d (0 = the measured default)
-    int merge_in_scan = -1;  // merge_in_scan = 0 | 1: candidate merge by the scan's last workgroups instead of a launch of its own (-1 = default)
+    int dual_scan = -1;      // pipe_dual_scan: -1 (default: with the masks, for scans shorter than 1 ms) | 1 (always) | 0 (never): main scans alternate between two streams, so the next scan's workgroups take over the CUs this
+                             // scan's workgroups leave (no idle gap between two scans); needs pipe_cu_mask, else the next scan would simply
+                             // occupy the CUs left free for the pre-phase
+    int cu_mask = -1;        // pipe_cu_mask = 1 (default on a 256-CU device) | 2 | 0 (off): the scan stream(s) are created with a CU mask of n_cu - 64 CUs, the pre-phase / merge streams
+                             // with the other 64 (1: mask bits interleave the XCDs — the amdgpu driver's enumeration; 2: 32 consecutive bits per XCD)
     int wide_abl = 0;        // development builds only
+    int dual_active = 0;     // read-only ("pipe_dual_scan_active"): did the last pipelined <= 64-query pass alternate between the two scan streams
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     // A row shard that took incremental appends holds several runs of consecutive global ids (cmr_index_set_id_blocks): the
     // kernels then run with base 0 and a remap launch translates their ids; candidate / row ids coming IN are translated
@@ -199,7 +207,8 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "pipe_reserve_cus") idx->reserve_cus = (int)v;
     else if (n == "pipe_slots") idx->pipe_slots = (int)v;
     else if (n == "wide_waves") { if (v != 0 && v != 4 && v != 8) return fail(CMR_ERR_INVALID, "wide_waves must be 0 (default), 4 or 8"); idx->wide_waves = (int)v; }
-    else if (n == "merge_in_scan") idx->merge_in_scan = (int)v;
+    else if (n == "pipe_dual_scan") idx->dual_scan = (int)v;
+    else if (n == "pipe_cu_mask") idx->cu_mask = (int)v;
 #ifdef CMR_DEV_KNOBS
     else if (n == "wide_abl") idx->wide_abl = (int)v;      // ablation kernels: results are WRONG by design (development builds only)
 #endif
@@ -212,7 +221,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
                                   "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_div", "sample_maxmul", "pipe_reserve_cus",
-                                  "pipe_slots", "wide_waves", "merge_in_scan", "wide_abl"};
+                                  "pipe_slots", "wide_waves", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
         for (const char* c = nm; *c; ++c) env += (char)toupper(*c);
@@ -606,11 +615,35 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
 }
 
 // Streams and per-slot events of the pipelined search, created on first use (idx->pipe_mu held).
-int ensure_pipe(Pipe& P) {
-    if (P.sp) return CMR_OK;
-    HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
+int ensure_pipe(cmr_index* idx) {
+    Pipe& P = idx->pipe;
+    if (P.sq) return CMR_OK;
+    const int mask = idx->cu_mask < 0 ? (idx->n_cu == 256 ? 1 : 0) : (idx->n_cu == 256 ? idx->cu_mask : 0);
+    const bool dual = idx->dual_scan < 0 ? mask != 0 : idx->dual_scan != 0;
     HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&P.wp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&P.wm, hipStreamNonBlocking));
+    if (mask) {
+        // Scans of the narrow kernel on n_cu - 64 CUs, their pre-phases on the other 64: the reservation that trimming the
+        // grid only approximates, made explicit — and the precondition for TWO scan streams: the next scan's workgroups then
+        // start on whatever CU of the scan set falls free (no idle gap, the tail of one scan under the ramp of the next),
+        // never on the pre-phase's CUs.  Measured (profiles/r3_pipe_cu_mask_dual_scan.txt): 1 M rows 0.270 -> 0.250 ms per
+        // step, 1.25 M 0.334 -> 0.308, 10 M 2.396 -> 2.331; masks alone <= 2 %, two streams without masks slower.
+        // Mask bit i is CU i of the driver's enumeration, which interleaves the XCDs: the first 192 bits are 24 CUs of each.
+        uint32_t scan[8], rest[8];
+        for (int w = 0; w < 8; ++w) {
+            scan[w] = mask == 2 ? 0x00FFFFFFu : (w < 6 ? 0xFFFFFFFFu : 0u);      // 2: 24 of every 32 bits (same split if 32 consecutive bits were one XCD)
+            rest[w] = ~scan[w];
+        }
+        HIP_TRY(hipExtStreamCreateWithCUMask(&P.sm, 8, scan));
+        if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&P.sm2, 8, scan));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&P.sp, 8, rest));
+        P.scan_cus = idx->n_cu - 64;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
+        if (dual) HIP_TRY(hipStreamCreateWithFlags(&P.sm2, hipStreamNonBlocking));
+    }
     for (int i = 0; i < CMR_PIPE_SLOTS; ++i) {
         HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
@@ -627,29 +660,44 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
                              float* max_dev, hipEvent_t wait_event, hipEvent_t* done_event) {
     std::lock_guard<std::mutex> pl(idx->pipe_mu);
     Pipe& P = idx->pipe;
-    { int rc_ = ensure_pipe(P); if (rc_) return rc_; }
+    { int rc_ = ensure_pipe(idx); if (rc_) return rc_; }
     P.nslots = std::min(CMR_PIPE_SLOTS, std::max(2, idx->pipe_slots));
-    if (wait_event) HIP_TRY(hipStreamWaitEvent(P.sp, wait_event, 0));
     if (k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "pipelined search supports k <= %d", CMR_MAX_K);
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
+    if (wait_event) {      // inputs ready: both pre-phase streams may read them
+        HIP_TRY(hipStreamWaitEvent(P.sp, wait_event, 0));
+        if (wideq > 0 && nq > narrow) HIP_TRY(hipStreamWaitEvent(P.wp, wait_event, 0));
+    }
     PipeSlot* last = nullptr;
     for (int q0 = 0; q0 < nq;) {
         const int left = nq - q0;
         const bool wide = wideq > 0 && left > narrow;
         const int nqp = std::min(wide ? wideq : narrow, left);
         PipeSlot* sl = &P.slot[P.next++ % (unsigned)P.nslots];
+        hipStream_t sp = wide ? P.wp : P.sp;
         if (sl->used) {
             // The pre-phase rewrites the slot's query fragments / thresholds: free once the slot's previous
             // main scan is over.  Its candidate lists are still being merged (on sq) at that point, so only the
             // new MAIN scan waits for that merge — a full scan period later, i.e. never in practice; that wait
             // sits at the END of the pre-phase (enqueue_pass, before pre_done is recorded): every wait packet on
             // the scan stream itself costs ~10 us between two main scans.
-            HIP_TRY(hipStreamWaitEvent(P.sp, sl->scan_done, 0));
+            HIP_TRY(hipStreamWaitEvent(sp, sl->scan_done, 0));
         }
-        int rc = enqueue_pass(idx, &sl->ws, P.sp, P.sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
-                              idx->reserve_cus,
+        // Two scan streams for the narrow kernel: consecutive main scans are not ordered by a stream any more — the second
+        // one's workgroups start as the first one's retire.  A slot's own scans stay ordered through its events (pre-phase ->
+        // scan -> merge -> next pre-phase), and nothing else is shared between two batches.
+        // Only short scans (< 1 ms at the streaming rate: shards up to ~4 M x 768 bf16 rows) alternate: there the ramp / tail /
+        // packet gap is 7-8 % of a step (1 M rows 0.270 -> 0.250 ms), at 10 M rows 2.7 % — and overlapping launches have no
+        // per-launch duration any more (a kernel's begin-to-end then includes the wait for the previous scan's CUs), which
+        // is what the roofline of the long headline scan is measured with.
+        const double scan_us = (double)((idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS) * idx->panel_bytes() / 6.0e6;
+        const bool dual = !wide && P.sm2 && (idx->dual_scan > 0 || scan_us < 1000.0);
+        idx->dual_active = dual ? 1 : 0;
+        hipStream_t sm = wide ? P.wm : ((dual && (P.nscan++ & 1)) ? P.sm2 : P.sm);
+        int rc = enqueue_pass(idx, &sl->ws, sp, sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
+                              (!wide && P.scan_cus) ? idx->n_cu - P.scan_cus : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
@@ -857,6 +905,9 @@ int32_t cmr_index_destroy(cmr_index_t* idx) {
         }
         if (idx->pipe.sp) (void)hipStreamDestroy(idx->pipe.sp);
         if (idx->pipe.sm) (void)hipStreamDestroy(idx->pipe.sm);
+        if (idx->pipe.sm2) (void)hipStreamDestroy(idx->pipe.sm2);
+        if (idx->pipe.wp) (void)hipStreamDestroy(idx->pipe.wp);
+        if (idx->pipe.wm) (void)hipStreamDestroy(idx->pipe.wm);
         if (idx->pipe.sq) (void)hipStreamDestroy(idx->pipe.sq);
         idx->stage.release();
         if (idx->h_pin) { (void)hipHostFree(idx->h_pin); idx->h_pin = nullptr; idx->h_pin_cap = 0; }
@@ -1032,6 +1083,17 @@ int32_t cmr_index_set_option(cmr_index_t* idx, const char* name, int64_t value) 
     return set_option(idx, name, value);
 }
 
+int32_t cmr_index_get_option(cmr_index_t* idx, const char* name, int64_t* value) {
+    if (!idx || !name || !value) return fail(CMR_ERR_INVALID, "NULL argument");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    const std::string n(name);
+    if (n == "pipe_dual_scan_active") *value = idx->dual_active;
+    else if (n == "pipe_cu_mask_active") *value = idx->pipe.scan_cus ? 1 : 0;
+    else if (n == "pipe_scan_cus") *value = idx->pipe.scan_cus ? idx->pipe.scan_cus : idx->n_cu;
+    else return fail(CMR_ERR_INVALID, "unknown readable option '%s'", name);
+    return CMR_OK;
+}
+
 int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream) {
     if (!idx || !stream) return fail(CMR_ERR_INVALID, "NULL argument");
     if (which < 0 || which > 2) return fail(CMR_ERR_INVALID, "which must be 0 (pre), 1 (scan) or 2 (post)");
@@ -1039,7 +1101,7 @@ int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream
     if (rc) return rc;
     std::lock_guard<std::mutex> pl(idx->pipe_mu);
     Pipe& P = idx->pipe;
-    rc = ensure_pipe(P);
+    rc = ensure_pipe(idx);
     if (rc) return rc;
     *stream = which == 0 ? (void*)P.sp : which == 1 ? (void*)P.sm : (void*)P.sq;
     return CMR_OK;
@@ -1055,7 +1117,10 @@ int32_t cmr_index_query_status(cmr_index_t* idx, int32_t* nonfinite) {
     {
         std::lock_guard<std::mutex> pl(idx->pipe_mu);
         for (int i = 0; i < CMR_PIPE_SLOTS; ++i) if (idx->pipe.slot[i].used) wss.push_back(&idx->pipe.slot[i].ws);
-        if (idx->pipe.sp) { HIP_TRY(hipStreamSynchronize(idx->pipe.sp)); HIP_TRY(hipStreamSynchronize(idx->pipe.sm)); HIP_TRY(hipStreamSynchronize(idx->pipe.sq)); }
+        if (idx->pipe.sq) {
+            for (hipStream_t st : {idx->pipe.sp, idx->pipe.sm, idx->pipe.sm2, idx->pipe.wp, idx->pipe.wm, idx->pipe.sq})
+                if (st) HIP_TRY(hipStreamSynchronize(st));
+        }
     }
     {
         std::lock_guard<std::mutex> g(idx->ws_mu);

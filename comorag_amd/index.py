@@ -44,6 +44,12 @@ class DenseIndex:
         """Route selector (cmr_index_set_option): picks between implementations that return the same results."""
         L.check(L.lib().cmr_index_set_option(self._h, name.encode(), int(value)))
 
+    def get_option(self, name: str) -> int:
+        """Read-only pipeline facts (cmr_index_get_option): "pipe_dual_scan_active", "pipe_cu_mask_active", "pipe_scan_cus"."""
+        v = C.c_int64(0)
+        L.check(L.lib().cmr_index_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
     # -- lifetime
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:

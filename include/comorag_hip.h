@@ -116,14 +116,14 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t n
                              int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
                              float* out_max_dev, void* stream);
 
-/* Throughput mode for a stream of independent query batches (serving; bench.py).  Work is enqueued
- * on two streams owned by the index: query packing + sampling passes of batch i+1 overlap the
- * HBM-bound main scan of batch i (main scans themselves are serialised and leave a few CUs free
- * for that).  wait_event (hipEvent_t or NULL): inputs are ready when it completes.  *done_event
- * (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded three
- * pipelined calls later (the pipeline has three slots), so wait on it (hipStreamWaitEvent /
- * hipEventSynchronize) before then.
- * k <= CMR_MAX_K.  Results are identical to cmr_index_search_dev.                               */
+/* Throughput mode for a stream of independent query batches (serving; bench.py).  Work is enqueued on streams owned by
+ * the index: query packing + sampling passes of batch i+1 overlap the HBM-bound main scan of batch i.  On a 256-CU device
+ * the main scans of batches of <= 64 queries run on a CU-masked pair of streams (n_cu - 64 CUs; consecutive scans alternate
+ * between the two, so one scan's workgroups take over the CUs the previous scan's workgroups leave) and their pre-phases on
+ * the other 64 CUs; wide batches use unmasked streams.  wait_event (hipEvent_t or NULL): inputs are ready when it
+ * completes.  *done_event (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded three
+ * pipelined calls later (the pipeline has three slots), so wait on it (hipStreamWaitEvent / hipEventSynchronize) before
+ * then.  k <= CMR_MAX_K.  Results are identical to cmr_index_search_dev.                                               */
 int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
                                    int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
                                    float* out_max_dev, void* wait_event, void** done_event);
@@ -144,12 +144,20 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * shipped library.  Names: scan_ring (8 | 16), scan_asm_ring (0 | 1), scan_grid, scan_no_sample, scan_no_wide (batches of
  * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
  * paths), zero_copy, sample_single, sample_div, sample_maxmul, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
- * waves per workgroup of the batch-256 kernel at 768-d), merge_in_scan (0 | 1).  Unknown names: CMR_ERR_INVALID.
+ * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0 | 1 | 2) and
+ * pipe_dual_scan (0 | 1; default: scans shorter than ~1 ms) — the pipelined search's streams with explicit CU masks (scans
+ * of <= 64-query batches on n_cu - 64 CUs, their pre-phases on the other 64) and two alternating scan streams; both must
+ * be set before the first pipelined call.
+ * Unknown names: CMR_ERR_INVALID.
  * The wide-batch kernel exists for padded dims 768 (256 queries per pass) and 1024 (128 per pass) in bf16 / f16; any other
  * dim and every fp32 index run a batch of B > 64 queries as ceil(B / 64) passes of the narrow kernel — same results.       */
 int32_t cmr_index_set_option(cmr_index_t* idx, const char* name, int64_t value);
-/* The pipeline's streams (which = 0 pre-phase, 1 main scans, 2 candidate merges / outputs) as
- * hipStream_t.  Work enqueued on stream 2 after a pipelined call is ordered after that call's
+/* What the pipeline actually does (read-only): "pipe_dual_scan_active" (the last pipelined <= 64-query pass alternated between
+ * the two scan streams: by default only scans shorter than ~1 ms do — launches that overlap have no per-launch duration, so a
+ * caller that times kernels must know), "pipe_cu_mask_active", "pipe_scan_cus".                                            */
+int32_t cmr_index_get_option(cmr_index_t* idx, const char* name, int64_t* value);
+/* The pipeline's streams (which = 0 pre-phase and 1 first main-scan stream of the <= 64-query batches, 2 candidate merges /
+ * outputs of every batch) as hipStream_t.  Work enqueued on stream 2 after a pipelined call is ordered after that call's
  * outputs and before the next use of the same output buffers (the RCCL exchange goes there).     */
 int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream);
 
