@@ -575,7 +575,7 @@ int small_path_kind(const cmr_index* idx, int nq, int k, bool threshold_search) 
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
     if (npanels > idx->small_max_panels) return 0;
     const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
-    if ((size_t)ks * 1024 > 147 * 1024) return 0;                    // the packed operands of one query tile (+ 13 KiB of static LDS) must fit
+    if ((size_t)ks * 1024 > 143 * 1024) return 0;                    // the packed operands of one query tile (+ 17 KiB of static LDS) must fit
     const int kind = cmr_tiny_kind(nq, (int)npanels, k, idx->tiny_multi, idx->small_max_panels);
     return (kind == 2 && idx->no_small) ? 0 : kind;
 }
@@ -1277,7 +1277,7 @@ int32_t cmr_index_scores(cmr_index_t* idx, const float* q, int32_t nq, float* ou
         const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
         const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
         const size_t sc_bytes = (size_t)nq * idx->n * 4, q_bytes = (size_t)nq * idx->dim * 4;
-        if (idx->zero_copy && !idx->no_tiny && !idx->no_small && nq <= 16 && npanels <= idx->small_max_panels && (size_t)ks * 1024 <= 147 * 1024 &&
+        if (idx->zero_copy && !idx->no_tiny && !idx->no_small && nq <= 16 && npanels <= idx->small_max_panels && (size_t)ks * 1024 <= 143 * 1024 &&
             sc_bytes <= 4 * kZeroCopyMax) {
             const size_t o_sc = 256, o_q = (o_sc + sc_bytes + 255) & ~(size_t)255;
             HIP_TRY(ws->ensure_pin(o_q + q_bytes));

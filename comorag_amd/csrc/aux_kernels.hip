@@ -409,8 +409,8 @@ hipError_t cmr_launch_merge_shards(const int64_t* ids, const float* scores, int 
 // "wave-wide arg-max, remove" cost ~1300 cycles each — 13 us at k = 20.  Instead the k-th largest of the 64 per-lane maxima
 // T is a lower bound of the k-th best key (k lanes hold a key >= T), so only keys >= T can win; those survivors (k .. a
 // few dozen) are compacted into one key per lane and ranked by counting — lane l's key goes to output position rank(l).
-// All cross-lane traffic is v_readlane.  More than 64 survivors (many lanes whose second best also beats T) or k > 64:
-// the rounds.  emit(rank, key) is called exactly once for every rank < k (key 0: no such row), by one lane.
+// All cross-lane traffic is v_readlane.  More than 64 survivors (many lanes whose second best also beats T) or k > 64: the
+// exact k-th key by a bitwise search (below).  emit(rank, key) is called exactly once for every rank < k (key 0: no such row), by one lane.
 __device__ __forceinline__ u64 tiny_readlane(u64 v, int l) {      // l wave-uniform
     return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, l);
 }
@@ -448,19 +448,41 @@ __device__ __forceinline__ void tiny_select(u64 (&key)[16], int k, u64* stage, i
             return;
         }
     }
-    for (int round = 0; round < k; ++round) {
-        u64 best = 0ull;
+    // k > 64 (BASELINE config 5 searches with k = 100), or more than 64 survivors above (k close to 64: the bound from the lane
+    // maxima is loose): the EXACT k-th largest key by a bitwise search — for bit 63 .. 0 try prefix | bit and count the keys
+    // >= it with ballots (16 compares + 16 population counts per bit, ~6 us in all) — then exactly min(k, n) survivors are
+    // compacted into two keys per lane and ranked by counting.  The k rounds of "arg-max, remove" this replaces cost ~1.5 us
+    // each: 160 us of a 205 us call at k = 100.
+    u64 T = 0ull;
+    for (int bit = 63; bit >= 0; --bit) {
+        const u64 trial = T | (1ull << bit);
+        int c = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) best = key[j] > best ? key[j] : best;
-        u64 wb = best;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(wb, off); wb = o > wb ? o : wb; }
-        if (wb != 0ull && best == wb) {          // keys are unique: exactly one lane, one slot
-#pragma unroll
-            for (int j = 0; j < 16; ++j) key[j] = key[j] == wb ? 0ull : key[j];
-        }
-        if (lane == 0) emit(round, wb);
+        for (int j = 0; j < 16; ++j) c += __popcll(__ballot(key[j] >= trial));
+        if (c >= k) T = trial;               // wave-uniform
     }
+    if (T == 0ull) T = 1ull;                 // fewer than k keys: every non-empty one survives
+    int S = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool sv = key[j] >= T;
+        const u64 m = __ballot(sv);
+        const int slot = S + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (sv) stage[slot] = key[j];         // S <= k <= 128: keys are unique, exactly min(k, n) of them are >= T
+        S += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const u64 m0 = lane < S ? stage[lane] : 0ull, m1 = lane + 64 < S ? stage[lane + 64] : 0ull;
+    int q0 = 0, q1 = 0;
+    const int S0 = S < 64 ? S : 64, S1 = S - S0;
+    for (int l = 0; l < S0; ++l) { const u64 o = tiny_readlane(m0, l); q0 += o > m0 ? 1 : 0; q1 += o > m1 ? 1 : 0; }
+    for (int l = 0; l < S1; ++l) { const u64 o = tiny_readlane(m1, l); q0 += o > m0 ? 1 : 0; q1 += o > m1 ? 1 : 0; }
+    if (m0 != 0ull) emit(q0, m0);
+    if (m1 != 0ull) emit(q1, m1);
+    for (int e = S + lane; e < k; e += 64) emit(e, 0ull);     // fewer than k rows with a score: the tail is empty
+    __builtin_amdgcn_wave_barrier();                             // the stage is reused by this wave's next query
 }
 
 // The same selection over a STREAM of n keys (fetch(i), 0 beyond n): one chunk of <= 1024 keys, or — k <= 64 — chunks of
@@ -525,7 +547,7 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
                                                           float* __restrict__ out_full, long long ld_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     __shared__ int ticket;
-    __shared__ u64 tiny_stage[8][64];       // per wave: the selection's surviving keys
+    __shared__ u64 tiny_stage[8][128];      // per wave: the selection's surviving keys (two per lane for 64 < k <= 128)
     __shared__ u64 tiny_carry[8][64];       // per wave: the running k best of a chunked selection
     __shared__ u64 tiny_fin[8][64];         // the last workgroup's per-wave pre-selections of the final round
     uint4* qf = reinterpret_cast<uint4*>(sm);                 // [nqt][ks][64], then (stage_raw) the fp32 queries [nq][dim]
@@ -698,7 +720,7 @@ static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int
         g.ppw = 8 * ((npanels + 8 * maxwg - 1) / (8 * maxwg));
         g.nwg = (npanels + g.ppw - 1) / g.ppw;
     }
-    constexpr size_t kDynLds = 160 * 1024 - 13 * 1024;                          // the kernel's static LDS (selection stage, carry and final rows) takes 12.3 KiB
+    constexpr size_t kDynLds = 160 * 1024 - 17 * 1024;                          // the kernel's static LDS (selection stage, carry and final rows) takes 16.3 KiB
     if (!g.kind || lds > kDynLds) return hipErrorInvalidValue;
     const int stage_raw = lds + (size_t)nq * dim * 4 <= kDynLds ? 1 : 0;          // fp32 at 1024-d: the operands alone take 128 KiB
     if (stage_raw) lds += (size_t)nq * dim * 4;
