@@ -1070,6 +1070,11 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
     HIP_TRY(hipMalloc((void**)&d, tab.size() * 8));
     HIP_TRY(hipMemcpy(d, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     if (idx->d_blk) idx->blk_retired.push_back(idx->d_blk);    // searches already enqueued keep reading the table they were given
+    if (idx->blk_retired.size() >= 8) {                        // ... until the device has drained: then the old tables go
+        HIP_TRY(hipDeviceSynchronize());
+        for (void* p : idx->blk_retired) (void)hipFree(p);
+        idx->blk_retired.clear();
+    }
     idx->d_blk = d;
     idx->blk_local.assign(local_start, local_start + n_blocks);
     idx->blk_global.assign(global_start, global_start + n_blocks);

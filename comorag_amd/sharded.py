@@ -15,8 +15,9 @@ are staged through the host around the collective.
 
 Incremental appends (`append`; BASELINE config 4 at N > 1): global ids stay dense in append order — what
 EmbeddingStore._upsert (embedding_store.py:122-128) and MemoryPool.add_node (utils/memory_utils.py:294-300) rely on —
-and an append goes to the currently shortest shard, so a shard holds several runs of consecutive global ids; the host-side
-table of those runs (`blocks`) is mirrored into the library with cmr_index_set_id_blocks.
+and appended rows go to the shards in blocks (a block of 8192 rows opens on the currently shortest shard and takes the appends
+until it is full), so a shard holds several runs of consecutive global ids; the host-side table of those runs (`blocks`) is
+mirrored into the library with cmr_index_set_id_blocks.
 """
 from __future__ import annotations
 
@@ -61,6 +62,7 @@ class ShardedIndex:
         self.blocks = [(0, self.base)]
         self.sizes = None
         self.total = None
+        self._cur = (None, 0)          # (shard taking appended rows, rows in its open block)
         self._owns_local = True
 
     def __len__(self):
@@ -86,23 +88,31 @@ class ShardedIndex:
         self.total = at
         return self
 
-    def _route(self, m: int, block_rows: int):
-        """[(shard, n rows)] for m appended rows: chunks of <= block_rows, each to the shortest shard at that moment (lowest
-        rank on ties) — deterministic, so every rank computes the same routing from the same table."""
+    def _route(self, m: int, block_rows: int, commit: bool = False):
+        """[(shard, n rows)] for m appended rows.  Rows keep going to the shard that took the previous ones until its current
+        block holds `block_rows` rows, then the block after it opens on the shortest shard at that moment (lowest rank on
+        ties): "round-robin blocks" of SURVEY §8e — shard sizes stay within one block of each other, and a shard's table of
+        id runs grows by one entry per block_rows appended rows, not per append (a memory pool appends 25 rows per cycle).
+        Deterministic from the replicated table, so every rank computes the same routing."""
         sizes = list(self.sizes)
+        cur, fill = self._cur
         out = []
         while m > 0:
-            n = min(m, block_rows)
-            t = min(range(self.world), key=lambda r: (sizes[r], r))
-            out.append((t, n))
-            sizes[t] += n
+            if cur is None or fill >= block_rows:
+                cur, fill = min(range(self.world), key=lambda r: (sizes[r], r)), 0
+            n = min(m, block_rows - fill)
+            out.append((cur, n))
+            sizes[cur] += n
+            fill += n
             m -= n
+        if commit:
+            self._cur = (cur, fill)
         return out
 
     def append(self, rows, block_rows: int = 8192) -> "np.ndarray":
         """Collective append of `rows` [m, dim] (numpy; every rank passes the same rows, only the owner of a chunk uploads
         it).  The rows get the global ids total .. total + m - 1 in order, exactly as one index would number them; returns
-        those ids.  Chunks of `block_rows` go to the currently shortest shard."""
+        those ids.  Blocks of `block_rows` rows go round robin to the shortest shard (`_route`)."""
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         if rows.ndim == 1:
             rows = rows[None, :]
@@ -112,7 +122,7 @@ class ShardedIndex:
         first = self.total
         at = 0
         changed = False
-        for shard, n in self._route(m, block_rows):
+        for shard, n in self._route(m, block_rows, commit=True):
             if shard == self.rank:
                 local_at = len(self.local)
                 self.local.append(rows[at:at + n])

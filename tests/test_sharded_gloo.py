@@ -128,8 +128,12 @@ def test_route_is_deterministic_and_balances():
         def __len__(self): return 0
     sh = ShardedIndex(8, "f32", rank=0, world=4, base=0, index=Local())
     sh.sizes, sh.total = [10, 7, 7, 12], 36
-    assert sh._route(5, 8192) == [(1, 5)]
-    assert sh._route(20, 8) == [(1, 8), (2, 8), (0, 4)]
+    assert sh._route(5, 8192) == [(1, 5)]                       # a new block opens on the shortest shard (lowest rank on ties)
+    assert sh._route(20, 8) == [(1, 8), (2, 8), (0, 4)]         # full blocks move on to the then-shortest shard
+    assert sh._route(3, 8, commit=True) == [(1, 3)]
+    sh.sizes[1] += 3
+    assert sh._route(4, 8) == [(1, 4)]                          # the open block keeps taking rows although shard 2 is shorter now
+    assert sh._route(9, 8) == [(1, 5), (2, 4)]
 
 
 def test_shard_bounds_cover_rows_exactly():
