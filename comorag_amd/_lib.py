@@ -47,6 +47,7 @@ SIGNATURES = {
     "cmr_index_append_dev": (_i32, [_p, _p, _i64, _p]),
     "cmr_index_search": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p]),
     "cmr_index_search_min_score": (_i32, [_p, _p, _i32, _i32, _f32, _p, _p]),
+    "cmr_index_search_min_score_dev": (_i32, [_p, _p, _i32, _i32, _f32, _p, _p, _p]),
     "cmr_index_search_dev": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cmr_index_search_pipelined": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _P(_p)]),
     "cmr_index_set_id_base": (_i32, [_p, _i64]),

@@ -1018,6 +1018,20 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, i
     return search_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev);
 }
 
+int32_t cmr_index_search_min_score_dev(cmr_index_t* idx, const float* q_dev, int32_t nq, int32_t k, float min_score, int64_t* ids_dev,
+                                       float* scores_dev, void* stream) {
+    if (!idx || !q_dev || !ids_dev || !scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "threshold search supports k in [1, %d]", CMR_MAX_K);
+    if (!(min_score == min_score)) return fail(CMR_ERR_INVALID, "min_score is NaN");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    Workspace* ws = acquire_ws(idx, (hipStream_t)stream, true);
+    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
+    return search_enqueue(idx, ws, q_dev, nq, k, ids_dev, scores_dev, nullptr, nullptr, &min_score);
+}
+
 int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_dev, int32_t nq, int32_t k, int64_t* ids_dev, float* scores_dev,
                                    float* min_dev, float* max_dev, void* wait_event, void** done_event) {
     if (!idx || !q_dev || !ids_dev || !scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");

@@ -123,6 +123,21 @@ class DenseIndex:
         L.check(L.lib().cmr_index_search_min_score(self._h, _ptr(q), nq, k, float(min_score), _ptr(ids), _ptr(sc)))
         return ids, sc
 
+    def search_min_score_dev(self, q_t, k: int, min_score: float, out_ids=None, out_scores=None, stream: Optional[int] = None):
+        """`search_min_score` on torch CUDA tensors, enqueued on torch's current stream without synchronising."""
+        import torch
+        assert q_t.is_cuda and q_t.dtype == torch.float32 and q_t.is_contiguous() and q_t.shape[1] == self.dim
+        nq, dev = q_t.shape[0], q_t.device
+        if out_ids is None:
+            out_ids = torch.empty((nq, k), dtype=torch.int64, device=dev)
+        if out_scores is None:
+            out_scores = torch.empty((nq, k), dtype=torch.float32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        L.check(L.lib().cmr_index_search_min_score_dev(self._h, C.c_void_p(q_t.data_ptr()), nq, k, float(min_score),
+                                                       C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_scores.data_ptr()), C.c_void_p(stream)))
+        return out_ids, out_scores
+
     def search_dev(self, q_t, k: int, out_ids=None, out_scores=None, out_min=None, out_max=None,
                    stream: Optional[int] = None):
         """Asynchronous search on torch CUDA tensors, enqueued on torch's current stream (also when that is the default

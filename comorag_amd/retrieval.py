@@ -131,10 +131,29 @@ def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, k
         results: Dict[str, Tuple[List[str], List[float]]] = {}
         from ._lib import CMR_MAX_K, CMR_MAX_K_2PASS
         thr_k = min(max_neighbours, CMR_MAX_K, kk)
+        thr_all = None
+        if min_score is not None and kk > thr_k and len(q) > query_batch_size:
+            # many query blocks (the synonymy self-join: every entity against every entity): queries go up ONCE, every block is
+            # enqueued on one stream without a synchronisation in between, the [nq, thr_k] results come back ONCE
+            import torch
+            dev = torch.device("cuda", device)
+            with torch.cuda.device(dev):
+                q_t = torch.from_numpy(q).to(dev)
+                ids_t = torch.empty((len(q), thr_k), dtype=torch.int64, device=dev)
+                sc_t = torch.empty((len(q), thr_k), dtype=torch.float32, device=dev)
+                for s in range(0, len(q), query_batch_size):
+                    e = min(s + query_batch_size, len(q))
+                    index.search_min_score_dev(q_t[s:e], thr_k, min_score, ids_t[s:e], sc_t[s:e])
+                torch.cuda.synchronize(dev)
+                if index.query_status():
+                    from ._lib import CMR_ERR_NONFINITE, CmrError
+                    raise CmrError(CMR_ERR_NONFINITE, "query contains NaN/Inf")
+                thr_all = (ids_t.cpu().numpy(), sc_t.cpu().numpy())
+                del q_t, ids_t, sc_t
         for s in range(0, len(q), query_batch_size):
             qb = q[s:s + query_batch_size]
             if min_score is not None and kk > thr_k:
-                ids, sc = index.search_min_score(qb, thr_k, min_score)
+                ids, sc = (thr_all[0][s:s + query_batch_size], thr_all[1][s:s + query_batch_size]) if thr_all is not None else index.search_min_score(qb, thr_k, min_score)
                 full = np.flatnonzero(ids[:, -1] >= 0)                  # lists that filled up: more neighbours may exist
                 redo = dict(zip(full.tolist(), zip(*index.search(qb[full], kk, with_minmax=False)[:2]))) if len(full) and kk <= CMR_MAX_K_2PASS else {}
                 for r in range(len(qb)):

@@ -112,6 +112,10 @@ int32_t cmr_index_search(cmr_index_t* idx, const float* q_f32, int32_t nq, int32
  * (:696-699), i.e. it reads ~1/20 of what the reference materialises.  k <= CMR_MAX_K.                                  */
 int32_t cmr_index_search_min_score(cmr_index_t* idx, const float* q_f32, int32_t nq, int32_t k, float min_score,
                                    int64_t* out_ids, float* out_scores);
+/* The same on device buffers, enqueued on `stream` without synchronising: the self-join issues one call per query block
+ * (queries uploaded once, results downloaded once) instead of an upload, a sync and a download per block.                 */
+int32_t cmr_index_search_min_score_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k, float min_score,
+                                       int64_t* out_ids_dev, float* out_scores_dev, void* stream);
 int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
                              int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
                              float* out_max_dev, void* stream);

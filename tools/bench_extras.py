@@ -234,8 +234,9 @@ def f1_selfjoin(torch, device, entities=200_000, dim=768, thr=0.8, batch=1024, c
     """the synonymy self-join of ComoRAG.add_synonymy_edges (ComoRAG.py:670-712) — every entity against every
     entity, neighbours with cosine >= 0.8 — by the threshold search (cmr_index_search_min_score) vs by materialising 2047
     neighbours per entity and cutting afterwards (what the reference asks retrieve_knn for), bf16 and fp32 storage.  Timed on
-    8 (threshold) / 2 (materialise) batches of 1024 queries and scaled to the whole join; the neighbours >= 0.8 of a batch are
-    compared between the two paths."""
+    the WHOLE join for the threshold path (device-resident queries, one stream, one sync), on 8 / 2 batches of 1024 queries
+    scaled to the whole join for the host-block variant and for materialise + select; the neighbours >= 0.8 of a batch are
+    compared between the paths."""
     from comorag_amd.index import DenseIndex
     g = torch.Generator(device=device); g.manual_seed(3)
     x = torch.randn((entities, dim), generator=g, device=device)
@@ -254,13 +255,27 @@ def f1_selfjoin(torch, device, entities=200_000, dim=768, thr=0.8, batch=1024, c
                 fn(xh[b * batch:(b + 1) * batch])
             return (time.perf_counter() - t0) / nb
         t_thr = run(lambda q: idx.search_min_score(q, 128, thr), 8)
+        # the WHOLE join the way retrieval.retrieve_knn(min_score=) runs it: queries resident on the device (they are the index's
+        # own rows), every block enqueued on one stream, one synchronisation, one download
+        ids_t = torch.empty((entities, 128), dtype=torch.int64, device=device); sc_t = torch.empty((entities, 128), dtype=torch.float32, device=device)
+        idx.search_min_score_dev(x[:batch], 128, thr, ids_t[:batch], sc_t[:batch]); torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for b0 in range(0, entities, batch):
+            b1 = min(b0 + batch, entities)
+            idx.search_min_score_dev(x[b0:b1], 128, thr, ids_t[b0:b1], sc_t[b0:b1])
+        torch.cuda.synchronize(device)
+        ids_h = ids_t.cpu().numpy()
+        t_join = time.perf_counter() - t0
+        del sc_t
         t_mat = run(lambda q: idx.search(q, 2047, with_minmax=False), 2)
         a = idx.search_min_score(xh[:batch], 128, thr); b = idx.search(xh[:batch], 2047, with_minmax=False)
         same = all(np.array_equal(a[0][i][a[0][i] >= 0], b[0][i][b[1][i] >= thr][:128]) for i in range(batch))
         scale = entities / batch
         peak = MFMA_BF16_PEAK_TFLOPS if dtype == "bf16" else F32_PEAK_TFLOPS
-        out[dtype] = {"threshold_search_s": t_thr * scale, "materialise_select_k2047_s": t_mat * scale, "speedup": t_mat / t_thr,
-                      "same_neighbours_above_threshold": bool(same), "TFLOPs": flops / (t_thr * scale) / 1e12, "frac": flops / (t_thr * scale) / 1e12 / peak,
+        same = same and bool(np.array_equal(ids_h[:batch], a[0]))
+        out[dtype] = {"threshold_search_whole_join_s": t_join, "threshold_search_host_blocks_s": t_thr * scale, "materialise_select_k2047_s": t_mat * scale,
+                      "speedup": t_mat * scale / t_join,
+                      "same_neighbours_above_threshold": bool(same), "TFLOPs": flops / t_join / 1e12, "frac": flops / t_join / 1e12 / peak,
                       # bytes each path writes per 1024-query batch, by construction: the threshold path writes candidate keys
                       # (8 B each, only scores >= thr) + [B,128] results; the other a [B, N] fp32 score block + [B,2047] results
                       "bytes_written_per_batch_threshold": int(batch * 128 * 12 + (a[0] >= 0).sum() * 8),
