@@ -249,7 +249,9 @@ def test_tokenizer_worker_process_returns_what_the_in_process_tokenizer_returns(
     want = tokenize_ragged(tok, texts, 512)
     assert max(len(x) for x in want) == 512 and min(len(x) for x in want) == 2
     _tokworker.init(tok.backend_tokenizer.to_str())
-    assert _tokworker.ragged(texts, 512) == want
-    assert _tokworker.ragged(texts[:3], 64) == tokenize_ragged(tok, texts[:3], 64)
+    as_lists = lambda arrays: [a.tolist() for a in arrays]
+    assert as_lists(_tokworker.ragged(texts, 512)) == want
+    assert as_lists(_tokworker.ragged(texts[:3], 64)) == tokenize_ragged(tok, texts[:3], 64)
     with mp.get_context("spawn").Pool(1, initializer=_tokworker.init, initargs=(tok.backend_tokenizer.to_str(),)) as pool:
-        assert pool.apply(_tokworker.ragged, (texts, 512)) == want
+        got = pool.apply(_tokworker.ragged, (texts, 512))
+        assert as_lists(got) == want and all(a.dtype == np.int32 for a in got)
