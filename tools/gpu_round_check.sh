@@ -8,4 +8,4 @@ echo "pytest rc=$?" >> gpurun_out/r3/check_pytest.log
 tail -4 gpurun_out/r3/check_pytest.log
 ( time timeout 600 python bench.py --steps 20 --warmup 5 ) > gpurun_out/r3/check_bench.json 2> gpurun_out/r3/check_bench.err
 echo "bench rc=$?"; tail -c 300 gpurun_out/r3/check_bench.err
-timeout 900 bash tools/collect_profiles_r3.sh > gpurun_out/r3/check_profiles.log 2>&1; tail -4 gpurun_out/r3/check_profiles.log
+timeout 900 bash tools/collect_profiles.sh > gpurun_out/r3/check_profiles.log 2>&1; tail -4 gpurun_out/r3/check_profiles.log
