@@ -167,6 +167,7 @@ struct cmr_index {
     int cu_mask = -1;        // pipe_cu_mask = 1 (default on a 256-CU device) | 2 | 0 (off): the scan stream(s) are created with a CU mask of n_cu - 64 CUs, the pre-phase / merge streams
                              // with the other 64 (1: mask bits interleave the XCDs — the amdgpu driver's enumeration; 2: 32 consecutive bits per XCD)
     int wide_abl = 0;        // development builds only
+    int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
     int dual_active = 0;     // read-only ("pipe_dual_scan_active"): did the last pipelined <= 64-query pass alternate between the two scan streams
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     // A row shard that took incremental appends holds several runs of consecutive global ids (cmr_index_set_id_blocks): the
@@ -202,6 +203,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "tiny_multi") idx->tiny_multi = (int)v;
     else if (n == "zero_copy") idx->zero_copy = (int)v;
     else if (n == "sample_single") idx->single_level = (int)v;
+    else if (n == "sample_tau_in_scan") idx->tau_in_scan = (int)v;
     else if (n == "sample_div") idx->sample_div = (int)std::max<long long>(2, v);
     else if (n == "sample_maxmul") idx->sample_maxmul = (int)std::max<long long>(0, v);
     else if (n == "pipe_reserve_cus") idx->reserve_cus = (int)v;
@@ -220,7 +222,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 // development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
-                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_tau_in_scan", "sample_div", "sample_maxmul", "pipe_reserve_cus",
                                   "pipe_slots", "wide_waves", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
@@ -426,6 +428,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     // Wide kernel: the sampling workgroups split the sampled panels among them (one list per workgroup and query).
     long long level_panels[2] = {0, 0};
     int n_levels = 0;
+    bool single_level = false;
     // threshold search (min_score): the caller's bound is the initial threshold of every query — already selective, so no
     // sampling passes
     if (!idx->no_sample && npanels >= 256 && !min_score) {
@@ -434,7 +437,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         // around a short scan: ONE sampling level of 128 panels instead of two saves a scan + merge pair (~45 us of a
         // 0.4 ms call at 1 M rows).  Its threshold lets ~k * npanels / 128 scores per query through — a few slow-path
         // entries per wave as long as queries x panels stays small.
-        const bool single_level = !wide && idx->single_level && k <= 32 && nqp <= 8 && npanels >= 4096 && (long long)nqp * npanels <= 320000;
+        single_level = !wide && idx->single_level && k <= 32 && nqp <= 8 && npanels >= 4096 && (long long)nqp * npanels <= 320000;
         level_panels[n_levels++] = single_level ? 128 : s0;
         if (npanels >= 4096 && !single_level) {
             // wide kernel: 256 queries share a workgroup, so ANY of 8 tiles beating its threshold stalls all four waves at
@@ -531,6 +534,15 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         as.sample_waves = (int)spn; as.sample_chunk_log2 = clog; as.sample_stride = (int)(npanels / nchunks);
         u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
         HIP_TRY(wide ? cmr_launch_scan_wide(gs, as, sp) : cmr_launch_scan_topk(gs, as, sp));
+        if (single_level && idx->tau_in_scan && NQ == 32 && nqp <= 2 && k <= 64) {
+            // the one sampling level of ONE or TWO queries (what a synchronous caller issues): the main scan's workgroups derive
+            // the thresholds from these lists themselves (scan_kernel) — no merge launch between the two scans.  Every
+            // workgroup reads the whole sample of its queries (32 KiB each): with 8 queries that costs more than the merge
+            // launch it saves (1 M rows: 371 -> 405 us per call), with one it wins (344 -> 330 us)
+            a.sample_lists = (const u64*)ws->s_lists.p; a.sample_cnt = (const int*)ws->s_cnt.p; a.sample_W = Wl;
+            a.tau_init = nullptr;
+            continue;
+        }
         HIP_TRY(cmr_launch_merge_query((const u64*)ws->s_lists.p, (const int*)ws->s_cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
                                        nullptr, nullptr, nullptr, tau_out, sp));
         a.tau_init = tau_out;

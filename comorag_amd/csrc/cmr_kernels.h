@@ -46,6 +46,11 @@ struct CmrScanArgs {
     int sample_stride;
     int sample_chunk_log2;
     const u64* tau_init;  // [nqt*32] initial threshold keys or nullptr
+    // narrow kernel, <= 8 queries, k <= 64: the main pass derives its thresholds ITSELF from the lists of a preceding sampling
+    // pass (sample_W lists of the same [W][32][cap] layout) instead of a merge launch between the two scans
+    const u64* sample_lists;
+    const int* sample_cnt;
+    int sample_W;
 };
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);

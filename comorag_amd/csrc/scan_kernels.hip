@@ -67,6 +67,9 @@ struct ScanP {
     int sample_stride;     //      (chunks of 2^c consecutive panels: one TLB reach / DRAM page run per chunk instead of per panel)
     int sample_chunk_log2;
     const u64* tau_init;   // per-query initial threshold keys (from the sampling pass) or nullptr
+    const u64* slists;     // lists / counters of a preceding sampling pass ([sW][32][CAP]): thresholds are derived in-kernel (nq <= 8, k <= 64)
+    const int* scnt;
+    int sW;
 };
 
 // Slow path, part 1 (inline, a handful of registers, no waits on global memory): push the keys of
@@ -179,6 +182,44 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         p1 = (int)(((long long)(gw + 1) * P.npanels) / W);
     }
 
+    // Thresholds straight from a sampling pass's lists (a handful of queries on a mid-size corpus: a synchronous caller's chain
+    // of dependent launches).  Wave w takes query w: every lane keeps the best key of "its" sample lists (lists lane, lane + 64,
+    // ...); the k-th largest of those 64 lane maxima is a lower bound of the k-th best key of the whole corpus — k lanes hold
+    // k distinct rows at or above it — and nearly as tight as the exact k-th best of the sample (the 20 best of 4096 sample keys
+    // sit in ~17 different lanes).  Every workgroup does this for itself (~2 us beside the query-tile fill): the merge launch
+    // between the two scans (21 us + its launch gap at 1 M rows) is gone.  Any valid lower bound leaves the results unchanged.
+    if constexpr (MODE == MODE_TOPK && NQT == 1) {
+        if (P.slists) {                          // wave-uniform
+            if (wave < P.nq) {
+                u64 best = 0ull;
+                for (int w = lane; w < P.sW; w += 64) {
+                    // a sampling wave scans ONE panel: <= 32 keys per list, read as 16 independent 16-byte loads (a list has room
+                    // for CAP >= 128 keys: in bounds whatever the count; keys beyond 32 would only be left out of the bound)
+                    const int c = P.scnt[(size_t)w * NQ + wave];
+                    const uint4* L4 = reinterpret_cast<const uint4*>(P.slists + ((size_t)w * NQ + wave) * CAP);
+                    uint4 v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = L4[i];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const u64 k0 = ((u64)v[i].y << 32) | v[i].x, k1 = ((u64)v[i].w << 32) | v[i].z;
+                        if (2 * i < c) best = k0 > best ? k0 : best;
+                        if (2 * i + 1 < c) best = k1 > best ? k1 : best;
+                    }
+                }
+                int rk = 0;
+                for (int l = 0; l < 64; ++l) {
+                    const u64 o = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(best >> 32), l) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)best, l);
+                    rk += o > best ? 1 : 0;
+                }
+                const u64 has = __ballot(best != 0ull && rk == P.k - 1);      // fewer than k lanes hold a key: no threshold
+                if (has && lane == __ffsll((long long)has) - 1) stage_all[(size_t)wave * (CAP + 2) + CAP + 1] = best - 1;
+                if (!has && lane == 0) stage_all[(size_t)wave * (CAP + 2) + CAP + 1] = 0ull;
+            }
+            __syncthreads();
+        }
+    }
+
     float rmin[NQT], rmax[NQT], tau_f[NQT];
     u64 tau_key[NQT];
 #pragma unroll
@@ -192,6 +233,9 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             if (q >= P.nq) {                     // padding query (all-zero operand): nothing may pass
                 tau_key[t] = ~0ull;
                 tau_f[t] = __builtin_inff();
+            } else if (NQT == 1 && P.slists) {   // derived above from the sampling pass's lists (q < nq <= 8 waves)
+                tau_key[t] = stage_all[(size_t)q * (CAP + 2) + CAP + 1];
+                if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
             } else if (P.tau_init) {             // a valid lower bound on the global k-th best key
                 tau_key[t] = P.tau_init[q];
                 if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
@@ -396,6 +440,7 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.lists = a.lists; p.cnt = a.cnt; p.mm = a.mm;
     p.scores = a.scores; p.ld = a.ld; p.nq = a.nq;
     p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.sample_chunk_log2 = a.sample_chunk_log2; p.tau_init = a.tau_init;
+    p.slists = a.sample_lists; p.scnt = a.sample_cnt; p.sW = a.sample_W;
     return p;
 }
 

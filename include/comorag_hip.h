@@ -147,7 +147,7 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * against each other bit for bit; tools A/B kernel decisions with them).  Nothing is read from the environment by the
  * shipped library.  Names: scan_ring (8 | 16), scan_asm_ring (0 | 1), scan_grid, scan_no_sample, scan_no_wide (batches of
  * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
- * paths), zero_copy, sample_single, sample_div, sample_maxmul, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
+ * paths), zero_copy, sample_single, sample_tau_in_scan, sample_div, sample_maxmul, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
  * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0 | 1 | 2) and
  * pipe_dual_scan (0 | 1; default: scans shorter than ~1 ms) — the pipelined search's streams with explicit CU masks (scans
  * of <= 64-query batches on n_cu - 64 CUs, their pre-phases on the other 64) and two alternating scan streams; both must

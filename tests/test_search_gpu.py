@@ -131,7 +131,8 @@ def test_zero_copy_host_api_equals_copy_path(n, nq, k):
     idx.close()
 
 
-@pytest.mark.parametrize("dtype,n,d,nq", [("bf16", 140_000, 128, 1), ("bf16", 140_000, 128, 8), ("f32", 131_072 + 5, 64, 3), ("bf16", 300_000, 64, 2)])
+@pytest.mark.parametrize("dtype,n,d,nq", [("bf16", 140_000, 128, 1), ("bf16", 140_000, 128, 8), ("f32", 131_072 + 5, 64, 3), ("bf16", 300_000, 64, 2),
+                                          ("f16", 200_000, 256, 1), ("f32", 150_001, 128, 2)])
 def test_small_batch_single_level_sampling(dtype, n, d, nq):
     """<= 8 queries on >= 128 Ki rows: one sampling level of 128 panels instead of two (CMR_SAMPLE_SINGLE=0 restores the
     two-level scheme).  A sample threshold is a lower bound of the true k-th best whatever the sample: same results."""
@@ -139,6 +140,16 @@ def test_small_batch_single_level_sampling(dtype, n, d, nq):
     a_ids, a_sc = _check(dtype, X, Q, 20)
     b_ids, b_sc = _check(dtype, X, Q, 20, env={"CMR_SAMPLE_SINGLE": "0"})
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+    # the single level's thresholds are derived by the main scan's workgroups from the sample lists (default) or by a merge
+    # launch between the two scans (sample_tau_in_scan = 0): any valid lower bound gives the same results; also with duplicated
+    # best rows (ties at the threshold), k = 1 and k = 32, and a corpus whose last sampled panel is partial
+    c_ids, c_sc = _check(dtype, X, Q, 20, env={"CMR_SAMPLE_TAU_IN_SCAN": "0"})
+    assert np.array_equal(a_ids, c_ids) and np.array_equal(a_sc, c_sc)
+    X2 = X.copy(); X2[5::7919] = X2[3]
+    for k in (1, 32):
+        d_ids, d_sc = _check(dtype, X2, Q, k)
+        e_ids, e_sc = _check(dtype, X2, Q, k, env={"CMR_SAMPLE_TAU_IN_SCAN": "0"})
+        assert np.array_equal(d_ids, e_ids) and np.array_equal(d_sc, e_sc)
 
 
 @pytest.mark.parametrize("dtype,d", [("bf16", 8), ("bf16", 128), ("bf16", 768), ("bf16", 1024), ("f16", 1024),
