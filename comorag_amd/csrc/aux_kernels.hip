@@ -135,12 +135,11 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 // case is a single chunk.
 //   sample pass (out_tau != nullptr): publishes (k-th best key) - 1 as the main scan's threshold
 //   main pass: writes ids/scores (+ id_base) and reduces the per-wave min/max partials.
-#define MERGE_THREADS 256
-#define MERGE_WAVES 4
-
-// Every thread holds up to MERGE_PER_THREAD (+1 carried) keys of the current chunk in registers.
-#define MERGE_PER_THREAD 16
-#define MERGE_POOL (MERGE_THREADS * MERGE_PER_THREAD)
+// Two shapes of the same kernel: 256 threads x 16 keys per thread (few lists: the sampling merges, the pipelined batches whose
+// merges run beside the next scan) and 1024 threads x 4 keys (a synchronous caller's main-pass merge over thousands of lists is
+// a latency chain behind the scan: the list-length prefix, the gather and every select pass touch a quarter of the slots per
+// thread).  MERGE_POOL keys per chunk either way.
+#define MERGE_POOL 4096
 
 // Radix select of the k largest keys held in the block's registers (MERGE_PER_THREAD+1 per
 // thread, 0 = empty): 8 passes over the key bytes, most significant first.  Each pass histograms
@@ -149,8 +148,10 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 // after the last pass the prefix IS the k-th largest key (keys are unique).  Keys >= it are
 // collected (exactly k of them) and ordered by rank counting.  Cost is independent of k.
 //   scratch: hist[256] ints, wsum[MERGE_WAVES] ints, sel[4] ints (digit, k_rem, winner counter, bin count), cand[k] u64
+template <int MERGE_THREADS, int MERGE_PER_THREAD>
 __device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1], int k, int* hist, int* wsum, int* sel,
                                                   u64* cand, u64* res) {
+    constexpr int MERGE_WAVES = MERGE_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // how many keys are there at all?
     int mine = 0;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1]
         int k_rem = k;
         for (int pass = 7; pass >= 0; --pass) {
             const int shift = pass * 8;
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
 #pragma unroll
             for (int j = 0; j <= MERGE_PER_THREAD; ++j) {
@@ -192,21 +193,21 @@ __device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1]
                 }
             }
             __syncthreads();
-            const int c = hist[tid];
+            const int c = tid < 256 ? hist[tid] : 0;      // 256 bins: the first four waves scan them
             int s = c;     // suffix sum inside the wave: bins tid..(wave end)
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const int o = __shfl_down(s, off);
                 if (lane + off < 64) s += o;
             }
-            if (lane == 0) wsum[wave] = s;
+            if (lane == 0 && wave < 4) wsum[wave] = s;
             __syncthreads();
             int higher = 0;
 #pragma unroll
-            for (int w = 0; w < MERGE_WAVES; ++w) higher += w > wave ? wsum[w] : 0;
+            for (int w = 0; w < 4; ++w) higher += w > wave ? wsum[w] : 0;
             const int S = s + higher;        // keys whose digit >= tid
             const int Sgt = S - c;           // keys whose digit >  tid
-            if (S >= k_rem && Sgt < k_rem) { sel[0] = tid; sel[1] = k_rem - Sgt; sel[3] = c; }
+            if (tid < 256 && S >= k_rem && Sgt < k_rem) { sel[0] = tid; sel[1] = k_rem - Sgt; sel[3] = c; }
             __syncthreads();
             pval |= (u64)(unsigned)sel[0] << shift;
             pmask |= 0xFFull << shift;
@@ -233,6 +234,7 @@ __device__ __forceinline__ void merge_select_regs(u64 (&e)[MERGE_PER_THREAD + 1]
     __syncthreads();
 }
 
+template <int MERGE_THREADS, int MERGE_PER_THREAD>
 __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* __restrict__ lists, const int* __restrict__ cnt,
                                                                     int W, int nq_stride, int cap, int k,
                                                                     const float2* __restrict__ mm, long long id_base,
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
     u64* cand = reinterpret_cast<u64*>(sm);                 // k
     u64* res = cand + k;                                    // k
     int* prefix = reinterpret_cast<int*>(res + k);          // W+1
+    constexpr int MERGE_WAVES = MERGE_THREADS / 64;
     int* wsum = prefix + (W + 1);                           // MERGE_WAVES
     int* hist = wsum + MERGE_WAVES;                         // 256
     int* sel = hist + 256;                                  // 4
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
             e[j] = v < total ? key : 0ull;
         }
         __syncthreads();     // every thread has read its carried key before the rounds rewrite res
-        merge_select_regs(e, k, hist, wsum, sel, cand, res);
+        merge_select_regs<MERGE_THREADS, MERGE_PER_THREAD>(e, k, hist, wsum, sel, cand, res);
         base += MERGE_POOL;
     } while (base < total);
 
@@ -346,14 +349,19 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
 hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
                                   float* out_min, float* out_max, u64* out_tau, hipStream_t s) {
-    if (W > 16 * MERGE_THREADS) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * k * 8 + (size_t)(W + 1) * 4 + MERGE_WAVES * 4 + 256 * 4 + 4 * 4 + 2 * MERGE_WAVES * 4;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(merge_query_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);     // a constant: per function, not per launch
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(merge_query_kernel, dim3(nq), dim3(MERGE_THREADS), lds, s, lists, cnt, W, nq_stride, cap, k, mm, id_base,
-                       out_ids, out_scores, out_min, out_max, out_tau);
-    return hipGetLastError();
+    if (W > 16 * 256) return hipErrorInvalidValue;
+    // a handful of queries over more than a thousand lists (a synchronous call's main pass): the 1024-thread shape
+    const bool big = nq <= 8 && W > 1024;
+    const int waves = big ? 16 : 4;
+    const size_t lds = (size_t)2 * k * 8 + (size_t)(W + 1) * 4 + waves * 4 + 256 * 4 + 4 * 4 + 2 * waves * 4;
+    auto launch = [&](auto kern, int threads) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);     // a constant: per function, not per launch
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(nq), dim3(threads), lds, s, lists, cnt, W, nq_stride, cap, k, mm, id_base, out_ids, out_scores, out_min, out_max, out_tau);
+        return hipGetLastError();
+    };
+    if (big) return launch(merge_query_kernel<1024, 4>, 1024);
+    return launch(merge_query_kernel<256, 16>, 256);
 }
 
 // Shard merge: ids/scores [S][nq][k] (global ids, -1 = empty) -> [nq][k], same order rule.
