@@ -61,3 +61,18 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "retrieval_np" not in src and "ref_loader" not in src, f
+
+
+def test_new_entry_points_reject_null_handles_without_a_device():
+    """The round's new symbols (options, id block table, communicator info, threshold search on device buffers) fail with
+    CMR_ERR_INVALID on NULL handles — no device call is made before the argument check, so this holds on a CPU-only host."""
+    lib = L.lib()
+    v = C.c_int64(0)
+    assert lib.cmr_index_set_option(None, b"scan_no_wide", 1) == L.CMR_ERR_INVALID
+    assert lib.cmr_index_get_option(None, b"pipe_scan_cus", C.byref(v)) == L.CMR_ERR_INVALID
+    a = np.zeros(2, np.int64)
+    assert lib.cmr_index_set_id_blocks(None, 2, a.ctypes.data, a.ctypes.data) == L.CMR_ERR_INVALID
+    w, r, n = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    assert lib.cmr_comm_info(None, C.byref(w), C.byref(r), C.byref(n)) == L.CMR_ERR_INVALID
+    assert lib.cmr_index_search_min_score_dev(None, None, 1, 1, 0.5, None, None, None) == L.CMR_ERR_INVALID
+    assert b"NULL" in lib.cmr_last_error()
