@@ -408,7 +408,7 @@ def main():
         shw = sh.view(ex256, timing=world > 1) if world > 1 else sh
         dtw, profw, lastw, qiw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl)
         _, _, same_w = verify_last_batch(shw, lastw, q256[qiw].cpu().numpy(), args.k)
-        c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim)       # wide batches never alternate
+        c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_wide_active")))
         c3["kernel"] = "scan_wide_kernel (256 queries resident in registers, LDS-DMA corpus ring)"
         c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
         c3["last_pipelined_batch_equals_synchronous_search"] = same_w
@@ -429,7 +429,7 @@ def main():
             except Exception as e:
                 out["exchange_bindings"]["rccl_ranks_seen"] = repr(e)[:200]
         mine = {"rank": rank, "rows": len(sh), "device": str(device), "batch64": {k_: head.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")},
-                "batch256": {k_: c3[k_] for k_ in ("kernel_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
+                "batch256": {k_: c3.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
         box = [None] * world
         dist.all_gather_object(box, mine)
         out["per_rank"] = box
@@ -464,7 +464,7 @@ def main():
                 steps2 = max(args.steps, 100)
                 dt2, prof2, _, _ = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device)
                 extra[f"{name}_{rows2}_rows_batch{b2}"] = summarise(b2, steps2, dt2, prof2, rows2, args.dim,
-                                                                     dual=b2 <= 64 and bool(sh2.local.get_option("pipe_dual_scan_active")))
+                                                                     dual=bool(sh2.local.get_option("pipe_dual_scan_active" if b2 <= 64 else "pipe_dual_scan_wide_active")))
             if name == "config2":
                 try:
                     lat = single_query_latency(torch, args, device)

@@ -119,7 +119,7 @@ struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullp
 // sp / sm / sm2: pre-phase and main scans of batches of <= 64 queries (with CU masks: sm, sm2 on n_cu - 64 CUs, sp on the other
 // 64); wp / wm: the same for wide batches (no masks: the wide kernel is matrix-pipe-bound and wants every CU); sq: candidate
 // merges and whatever the caller appends behind a batch (no mask: its small workgroups fit beside a scan workgroup on any CU)
-struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sm2 = nullptr, wp = nullptr, wm = nullptr, sq = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; unsigned nscan = 0; int scan_cus = 0; };
+struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sm2 = nullptr, wp = nullptr, wm = nullptr, wm2 = nullptr, sq = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; unsigned nscan = 0, nwscan = 0; int scan_cus = 0, wide_cus = 0; };
 
 }  // namespace
 
@@ -168,6 +168,7 @@ struct cmr_index {
                              // with the other 64 (1: mask bits interleave the XCDs — the amdgpu driver's enumeration; 2: 32 consecutive bits per XCD)
     int wide_abl = 0;        // development builds only
     int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
+    int dual_wide_active = 0;   // read-only ("pipe_dual_scan_wide_active"): the same for the last wide pass
     int dual_active = 0;     // read-only ("pipe_dual_scan_active"): did the last pipelined <= 64-query pass alternate between the two scan streams
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
     // A row shard that took incremental appends holds several runs of consecutive global ids (cmr_index_set_id_blocks): the
@@ -633,8 +634,22 @@ int ensure_pipe(cmr_index* idx) {
     const int mask = idx->cu_mask < 0 ? (idx->n_cu == 256 ? 1 : 0) : (idx->n_cu == 256 ? idx->cu_mask : 0);
     const bool dual = idx->dual_scan < 0 ? mask != 0 : idx->dual_scan != 0;
     HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&P.wp, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&P.wm, hipStreamNonBlocking));
+    if (mask) {
+        // wide batches: the matrix-pipe-bound kernel wants CUs — n_cu - 32 for its scans (28 per XCD), the 32 it used to leave
+        // free by trimming its grid for the pre-phase; two scan streams for short scans as below
+        uint32_t wscan[8], wrest[8];
+        for (int w = 0; w < 8; ++w) {
+            wscan[w] = mask == 2 ? 0x0FFFFFFFu : (w < 7 ? 0xFFFFFFFFu : 0u);
+            wrest[w] = ~wscan[w];
+        }
+        HIP_TRY(hipExtStreamCreateWithCUMask(&P.wm, 8, wscan));
+        if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&P.wm2, 8, wscan));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&P.wp, 8, wrest));
+        P.wide_cus = idx->n_cu - 32;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&P.wp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.wm, hipStreamNonBlocking));
+    }
     if (mask) {
         // Scans of the narrow kernel on n_cu - 64 CUs, their pre-phases on the other 64: the reservation that trimming the
         // grid only approximates, made explicit — and the precondition for TWO scan streams: the next scan's workgroups then
@@ -705,11 +720,12 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         // per-launch duration any more (a kernel's begin-to-end then includes the wait for the previous scan's CUs), which
         // is what the roofline of the long headline scan is measured with.
         const double scan_us = (double)((idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS) * idx->panel_bytes() / 6.0e6;
-        const bool dual = !wide && P.sm2 && (idx->dual_scan > 0 || scan_us < 1000.0);
-        idx->dual_active = dual ? 1 : 0;
-        hipStream_t sm = wide ? P.wm : ((dual && (P.nscan++ & 1)) ? P.sm2 : P.sm);
+        const bool dual = (wide ? P.wm2 != nullptr : P.sm2 != nullptr) && (idx->dual_scan > 0 || scan_us < 1000.0);
+        if (!wide) idx->dual_active = dual ? 1 : 0;
+        else idx->dual_wide_active = dual ? 1 : 0;
+        hipStream_t sm = wide ? ((dual && (P.nwscan++ & 1)) ? P.wm2 : P.wm) : ((dual && (P.nscan++ & 1)) ? P.sm2 : P.sm);
         int rc = enqueue_pass(idx, &sl->ws, sp, sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
-                              (!wide && P.scan_cus) ? idx->n_cu - P.scan_cus : idx->reserve_cus,
+                              (!wide && P.scan_cus) ? idx->n_cu - P.scan_cus : (wide && P.wide_cus) ? idx->n_cu - P.wide_cus : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
@@ -920,6 +936,7 @@ int32_t cmr_index_destroy(cmr_index_t* idx) {
         if (idx->pipe.sm2) (void)hipStreamDestroy(idx->pipe.sm2);
         if (idx->pipe.wp) (void)hipStreamDestroy(idx->pipe.wp);
         if (idx->pipe.wm) (void)hipStreamDestroy(idx->pipe.wm);
+        if (idx->pipe.wm2) (void)hipStreamDestroy(idx->pipe.wm2);
         if (idx->pipe.sq) (void)hipStreamDestroy(idx->pipe.sq);
         idx->stage.release();
         if (idx->h_pin) { (void)hipHostFree(idx->h_pin); idx->h_pin = nullptr; idx->h_pin_cap = 0; }
@@ -1119,6 +1136,7 @@ int32_t cmr_index_get_option(cmr_index_t* idx, const char* name, int64_t* value)
     std::shared_lock<std::shared_mutex> lk(idx->mu);
     const std::string n(name);
     if (n == "pipe_dual_scan_active") *value = idx->dual_active;
+    else if (n == "pipe_dual_scan_wide_active") *value = idx->dual_wide_active;
     else if (n == "pipe_cu_mask_active") *value = idx->pipe.scan_cus ? 1 : 0;
     else if (n == "pipe_scan_cus") *value = idx->pipe.scan_cus ? idx->pipe.scan_cus : idx->n_cu;
     else return fail(CMR_ERR_INVALID, "unknown readable option '%s'", name);
@@ -1149,7 +1167,7 @@ int32_t cmr_index_query_status(cmr_index_t* idx, int32_t* nonfinite) {
         std::lock_guard<std::mutex> pl(idx->pipe_mu);
         for (int i = 0; i < CMR_PIPE_SLOTS; ++i) if (idx->pipe.slot[i].used) wss.push_back(&idx->pipe.slot[i].ws);
         if (idx->pipe.sq) {
-            for (hipStream_t st : {idx->pipe.sp, idx->pipe.sm, idx->pipe.sm2, idx->pipe.wp, idx->pipe.wm, idx->pipe.sq})
+            for (hipStream_t st : {idx->pipe.sp, idx->pipe.sm, idx->pipe.sm2, idx->pipe.wp, idx->pipe.wm, idx->pipe.wm2, idx->pipe.sq})
                 if (st) HIP_TRY(hipStreamSynchronize(st));
         }
     }

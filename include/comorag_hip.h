@@ -122,9 +122,9 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t n
 
 /* Throughput mode for a stream of independent query batches (serving; bench.py).  Work is enqueued on streams owned by
  * the index: query packing + sampling passes of batch i+1 overlap the HBM-bound main scan of batch i.  On a 256-CU device
- * the main scans of batches of <= 64 queries run on a CU-masked pair of streams (n_cu - 64 CUs; consecutive scans alternate
- * between the two, so one scan's workgroups take over the CUs the previous scan's workgroups leave) and their pre-phases on
- * the other 64 CUs; wide batches use unmasked streams.  wait_event (hipEvent_t or NULL): inputs are ready when it
+ * the main scans of batches of <= 64 queries run on a CU-masked pair of streams (n_cu - 64 CUs; consecutive scans shorter than
+ * ~1 ms alternate between the two, so one scan's workgroups take over the CUs the previous scan's workgroups leave) and their
+ * pre-phases on the other 64 CUs; wide batches likewise on n_cu - 32 / 32 CUs.  wait_event (hipEvent_t or NULL): inputs are ready when it
  * completes.  *done_event (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded three
  * pipelined calls later (the pipeline has three slots), so wait on it (hipStreamWaitEvent / hipEventSynchronize) before
  * then.  k <= CMR_MAX_K.  Results are identical to cmr_index_search_dev.                                               */
@@ -156,7 +156,7 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * The wide-batch kernel exists for padded dims 768 (256 queries per pass) and 1024 (128 per pass) in bf16 / f16; any other
  * dim and every fp32 index run a batch of B > 64 queries as ceil(B / 64) passes of the narrow kernel — same results.       */
 int32_t cmr_index_set_option(cmr_index_t* idx, const char* name, int64_t value);
-/* What the pipeline actually does (read-only): "pipe_dual_scan_active" (the last pipelined <= 64-query pass alternated between
+/* What the pipeline actually does (read-only): "pipe_dual_scan_active" / "pipe_dual_scan_wide_active" (the last pipelined <= 64-query / wide pass alternated between
  * the two scan streams: by default only scans shorter than ~1 ms do — launches that overlap have no per-launch duration, so a
  * caller that times kernels must know), "pipe_cu_mask_active", "pipe_scan_cus".                                            */
 int32_t cmr_index_get_option(cmr_index_t* idx, const char* name, int64_t* value);

@@ -31,9 +31,9 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] is True
     assert out["exchange_bindings"]["backend"] == "gloo" and out["exchange_bindings"]["torch_world_size"] == 2
     assert [p["rank"] for p in out["per_rank"]] == [0, 1] and sum(p["rows"] for p in out["per_rank"]) == 300000
-    # 150 K-row shards are short scans: the B = 64 passes alternate between the two scan streams (no per-launch duration,
-    # a lifetime instead); the wide B = 256 passes never do
-    assert all((p["batch64"]["kernel_ms"] or p["batch64"]["kernel_lifetime_ms"]) > 0 and p["batch256"]["kernel_ms"] > 0 for p in out["per_rank"])
+    # 150 K-row shards are short scans: the passes alternate between two scan streams (no per-launch duration, a lifetime
+    # instead)
+    assert all((p[b]["kernel_ms"] or p[b]["kernel_lifetime_ms"]) > 0 for p in out["per_rank"] for b in ("batch64", "batch256"))
     assert out["roofline"]["two_scan_streams"] is True and out["roofline"]["kernel_ms"] is None
     assert out["extra"]["config3_batch256"]["last_pipelined_batch_equals_synchronous_search"] is True
     assert out["roofline"]["rows_per_gpu"] == 150000
