@@ -1583,6 +1583,36 @@ int32_t cmr_pool_l2norm(int32_t device_id, const void* hidden_dev, int32_t hidde
     return CMR_OK;
 }
 
+int32_t cmr_encoder_attention(int32_t device_id, const void* qkv_dev, int32_t dtype, const int32_t* lens_dev, int32_t b, int32_t l,
+                              int32_t n_heads, int32_t head_dim, void* out_dev, void* stream) {
+    if (!qkv_dev || !lens_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (b <= 0 || l <= 0 || n_heads <= 0) return fail(CMR_ERR_INVALID, "b, l, n_heads must be > 0");
+    if (head_dim != 64) return fail(CMR_ERR_INVALID, "cmr_encoder_attention: head_dim must be 64 (BERT-base / BERT-large heads)");
+    if (dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "cmr_encoder_attention: dtype must be bf16 or f16");
+    if (((uintptr_t)qkv_dev | (uintptr_t)out_dev) & 15) return fail(CMR_ERR_INVALID, "cmr_encoder_attention: buffers must be 16-byte aligned");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    HIP_TRY(cmr_launch_attention(qkv_dev, dtype, lens_dev, b, l, n_heads, out_dev, (hipStream_t)stream));
+    return CMR_OK;
+}
+
+int32_t cmr_encoder_add_layernorm(int32_t device_id, const void* y_dev, const void* bias_dev, const void* residual_dev, const void* gamma_dev,
+                                  const void* beta_dev, float eps, int64_t rows, int32_t d, int32_t dtype, void* out_dev, void* stream) {
+    if (!y_dev || !gamma_dev || !beta_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (rows <= 0 || d <= 0 || d % 4 || d > 2048) return fail(CMR_ERR_INVALID, "cmr_encoder_add_layernorm: rows > 0, d a multiple of 4, d <= 2048");
+    if (dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "cmr_encoder_add_layernorm: dtype must be bf16 or f16");
+    if (((uintptr_t)y_dev | (uintptr_t)bias_dev | (uintptr_t)residual_dev | (uintptr_t)gamma_dev | (uintptr_t)beta_dev | (uintptr_t)out_dev) & 7)
+        return fail(CMR_ERR_INVALID, "cmr_encoder_add_layernorm: buffers must be 8-byte aligned");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    HIP_TRY(cmr_launch_add_layernorm(y_dev, bias_dev, residual_dev, gamma_dev, beta_dev, eps, rows, d, dtype, out_dev, (hipStream_t)stream));
+    return CMR_OK;
+}
+
 int32_t cmr_profile_enable(cmr_index_t* idx, int32_t on) {
     if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
     std::lock_guard<std::mutex> g(idx->prof_mu);

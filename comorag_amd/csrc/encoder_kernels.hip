@@ -1,0 +1,333 @@
+// Encoder-side gfx950 kernels of libcomorag_hip.so: the two memory-/latency-shaped pieces of a BERT layer that are not GEMMs.
+//
+//   attn_fwd_kernel   softmax(Q K^T / sqrt(64)) V of one (sequence, head, 128-query block) per workgroup, 16-bit in / out,
+//                     fp32 scores and accumulators, keys beyond the sequence's length masked (right-padded mini-batches).
+//                     Replaces the scaled-dot-product-attention call inside transformers' BertSelfAttention, i.e. part of
+//                     `self.embedding_model(**inputs)` at embedding_model/BGEEmbedding.py:119.
+//   add_ln_kernel     LayerNorm(y + bias + residual) * gamma + beta, one wave per token: BertSelfOutput / BertOutput minus
+//                     their GEMM (dense bias add, residual add and LayerNorm are three kernels and five passes over the
+//                     activations in PyTorch; here one read of y and the residual, one write).
+//
+// Attention layout.  Q, K, V are column slices of ONE packed projection output qkv[b*L, 3*hidden] (the host side multiplies by
+// the concatenated query/key/value weights once): head h reads columns h*64 (Q), hidden + h*64 (K), 2*hidden + h*64 (V).
+// A wave owns 32 query rows.  Scores are computed TRANSPOSED, S^T = K Q^T (A operand = a 32-key tile read from LDS, B operand
+// = the wave's Q rows, loaded once from global memory in MFMA lane order), so that in the 32x32 accumulator layout
+// (cmr_acc_row) lane l holds column q = l & 31: every softmax statistic of a query row is lane-local except one cross-half
+// max.  The same registers, converted to 16 bits, ARE the B operand of O^T = V^T P^T: k-slot e of lane half g is key
+// acc_row(8*s + e, g) — a permutation of the 16 keys of a k-step, applied identically to the A operand by reading V^T from
+// LDS at [d][16*s + 4*g + {0..3}] and [d][16*s + 8 + 4*g + {0..3}].  V is transposed on its way into LDS (two keys per thread,
+// eight packed 4-byte writes); K goes in row-major.  Both are double-buffered 64-key chunks: the global loads of chunk c + 1
+// are in flight while chunk c is multiplied, one barrier per chunk.  35 KiB of LDS per workgroup: several workgroups share a
+// CU, so one's exponentials overlap another's MFMAs (the 64-wide head makes the softmax, not the matrix pipe, the longer leg).
+#include "cmr_device.h"
+#include "cmr_kernels.h"
+
+typedef __attribute__((ext_vector_type(2))) __bf16 enc_bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 enc_f16x2;
+
+template <int DT> __device__ __forceinline__ unsigned enc_pack2(float a, float b) {   // round-to-nearest-even, a in the low half
+    if constexpr (DT == CMR_DT_BF16) {
+        enc_bf16x2 t;
+        t[0] = (__bf16)a;
+        t[1] = (__bf16)b;
+        return __builtin_bit_cast(unsigned, t);
+    } else {
+        enc_f16x2 t;
+        t[0] = (_Float16)a;
+        t[1] = (_Float16)b;
+        return __builtin_bit_cast(unsigned, t);
+    }
+}
+template <int DT> __device__ __forceinline__ void enc_unpack2(unsigned u, float& a, float& b) {
+    if constexpr (DT == CMR_DT_BF16) {
+        a = __uint_as_float(u << 16);
+        b = __uint_as_float(u & 0xFFFF0000u);
+    } else {
+        enc_f16x2 t = __builtin_bit_cast(enc_f16x2, u);
+        a = (float)t[0];
+        b = (float)t[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+#define ATT_CHUNK 64          // keys per LDS chunk
+#define ATT_QBLOCK 128        // query rows per workgroup (4 waves x 32)
+#define ATT_KSTR 72           // K rows in LDS: 64 elements + 8 of padding (144 B: ds_read_b128 of 16 consecutive rows hit 16 different 16-B slots)
+#define ATT_VSTR 68           // V^T rows in LDS: 64 keys + 4 (136 B: ds_read_b64 of 32 consecutive d rows hit 32 different bank pairs)
+#define ATT_NEG (-1.0e30f)
+
+template <int DT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ lens, int L, int hidden,
+                                                           int n_heads, int n_qblocks, int total, float sc /* log2(e) / sqrt(64) */,
+                                                           unsigned short* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned short k_lds[2][ATT_CHUNK * ATT_KSTR];
+    __shared__ __attribute__((aligned(16))) unsigned short v_lds[2][64 * ATT_VSTR];
+    // workgroup id -> work item: consecutive items (the query blocks of one head, the heads of one sequence) stay on ONE XCD
+    // (hardware deals workgroup ids round-robin over the 8 XCDs), so a head's K / V come out of that XCD's L2 after the first block
+    const int per = (total + 7) >> 3;
+    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (item >= total) return;
+    const int qb = item % n_qblocks, head = (item / n_qblocks) % n_heads, seq = item / (n_qblocks * n_heads);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c = lane & 31;
+    const int q0 = qb * ATT_QBLOCK;
+    int len = lens[seq];
+    len = len < L ? len : L;
+    const size_t rs = (size_t)3 * hidden;
+    const unsigned short* qbase = qkv + (size_t)seq * L * rs + (size_t)head * 64;
+    const unsigned short* kbase = qbase + hidden;
+    const unsigned short* vbase = qbase + 2 * (size_t)hidden;
+    unsigned short* obase = out + (size_t)seq * L * hidden + (size_t)head * 64;
+
+    if (q0 >= len) {                                   // a block of padding rows only: zeros, nothing reads them but LayerNorm
+        const int row = q0 + (tid >> 1);
+        if (row < L) {
+            uint4* dst = reinterpret_cast<uint4*>(obase + (size_t)row * hidden + (tid & 1) * 32);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            dst[0] = z; dst[1] = z; dst[2] = z; dst[3] = z;
+        }
+        return;
+    }
+
+    // the wave's 32 query rows as B operands of the four k-steps over d (lane: row c, d = 16*ks + 8*g + [0,8))
+    const int qrow = q0 + wave * 32 + c;
+    v4u qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = v4u{0, 0, 0, 0};
+        if (qrow < L) qf[ks] = *reinterpret_cast<const v4u*>(qbase + (size_t)qrow * rs + ks * 16 + g * 8);
+    }
+
+    // chunk staging.  K: thread -> rows r and r + 32, 16-byte segment seg.  V: thread -> the key pair pi, d segment dseg.
+    const int kr = tid >> 3, kseg = tid & 7;
+    const int pi = wave * 8 + (lane & 7), dseg = lane >> 3;
+    v4u kreg[2], vreg[2];
+    auto load_chunk = [&](int ch) {
+        const int k0 = ch * ATT_CHUNK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int key = k0 + kr + 32 * h;
+            kreg[h] = v4u{0, 0, 0, 0};
+            if (key < len) kreg[h] = *reinterpret_cast<const v4u*>(kbase + (size_t)key * rs + kseg * 8);
+            const int vkey = k0 + 2 * pi + h;
+            vreg[h] = v4u{0, 0, 0, 0};
+            if (vkey < len) vreg[h] = *reinterpret_cast<const v4u*>(vbase + (size_t)vkey * rs + dseg * 8);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + 32 * h) * ATT_KSTR + kseg * 8]) = kreg[h];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                  // element 2w and 2w + 1 of both keys -> V^T[d][key0], V^T[d][key0 + 1]
+            const unsigned a = vreg[0][w], b = vreg[1][w];
+            *reinterpret_cast<unsigned*>(&v_lds[buf][(dseg * 8 + 2 * w) * ATT_VSTR + 2 * pi]) = (a & 0xFFFFu) | (b << 16);
+            *reinterpret_cast<unsigned*>(&v_lds[buf][(dseg * 8 + 2 * w + 1) * ATT_VSTR + 2 * pi]) = (a >> 16) | (b & 0xFFFF0000u);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
+    float m = ATT_NEG, lsum = 0.0f;
+    const int nch = (len + ATT_CHUNK - 1) / ATT_CHUNK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int cur = ch & 1;
+        if (ch + 1 < nch) load_chunk(ch + 1);
+        // S^T tiles: keys t*32 + [0,32) of the chunk x the wave's 32 queries
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4u kf = *reinterpret_cast<const v4u*>(&k_lds[cur][(t * 32 + c) * ATT_KSTR + ks * 16 + g * 8]);
+                s[t] = CmrBlk<DT>::mma(kf, qf[ks], s[t]);
+            }
+        }
+        const int k0 = ch * ATT_CHUNK;
+        if (k0 + ATT_CHUNK > len) {                    // the chunk holding the end of the sequence (wave-uniform)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + t * 32 + cmr_acc_row(r, lane) >= len) s[t][r] = ATT_NEG;
+        }
+        float cm = ATT_NEG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cm = fmaxf(cm, s[t][r]);
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * sc);
+        const float msc = mn * sc;
+        float ps = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -msc));
+                s[t][r] = p;
+                ps += p;
+            }
+        lsum = fmaf(lsum, alpha, ps);
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        // O^T += V^T P^T: four k-steps of 16 keys; the P registers 8*sp .. 8*sp + 7 of tile t are the B operand as they are
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                v4u pb;
+                pb[0] = enc_pack2<DT>(s[t][8 * sp + 0], s[t][8 * sp + 1]);
+                pb[1] = enc_pack2<DT>(s[t][8 * sp + 2], s[t][8 * sp + 3]);
+                pb[2] = enc_pack2<DT>(s[t][8 * sp + 4], s[t][8 * sp + 5]);
+                pb[3] = enc_pack2<DT>(s[t][8 * sp + 6], s[t][8 * sp + 7]);
+                const int kb = t * 32 + sp * 16 + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const unsigned short* vrow = &v_lds[cur][(dt * 32 + c) * ATT_VSTR + kb];
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
+                    o[dt] = CmrBlk<DT>::mma(v4u{lo.x, lo.y, hi.x, hi.y}, pb, o[dt]);
+                }
+            }
+        if (ch + 1 < nch) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+    const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
+    if (qrow < L) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {           // registers 4*rr .. 4*rr + 3 = d columns dt*32 + 8*rr + 4*g + [0,4)
+                uint2 w;
+                w.x = enc_pack2<DT>(o[dt][4 * rr + 0] * inv, o[dt][4 * rr + 1] * inv);
+                w.y = enc_pack2<DT>(o[dt][4 * rr + 2] * inv, o[dt][4 * rr + 3] * inv);
+                *reinterpret_cast<uint2*>(obase + (size_t)qrow * hidden + dt * 32 + 8 * rr + 4 * g) = w;
+            }
+    }
+}
+
+hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int b, int L, int n_heads, void* out, hipStream_t s) {
+    const int hidden = n_heads * 64;
+    const int n_qblocks = (L + ATT_QBLOCK - 1) / ATT_QBLOCK;
+    const long long total = (long long)n_qblocks * n_heads * b;
+    if (total > (1LL << 28)) return hipErrorInvalidValue;
+    const int per = (int)((total + 7) / 8);
+    const float sc = 1.4426950408889634f * 0.125f;
+    const dim3 grid((unsigned)(per * 8)), block(256);
+    if (dtype == CMR_DT_BF16)
+        hipLaunchKernelGGL(attn_fwd_kernel<CMR_DT_BF16>, grid, block, 0, s, reinterpret_cast<const unsigned short*>(qkv), lens, L, hidden, n_heads,
+                           n_qblocks, (int)total, sc, reinterpret_cast<unsigned short*>(out));
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel<CMR_DT_F16>, grid, block, 0, s, reinterpret_cast<const unsigned short*>(qkv), lens, L, hidden, n_heads,
+                           n_qblocks, (int)total, sc, reinterpret_cast<unsigned short*>(out));
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ bias + residual + LayerNorm
+// One wave per token row, d = 4 * d4 elements, lane holds vectors lane, lane + 64, ... (8-byte loads: a wave instruction reads
+// 512 contiguous bytes).  Sum, mean and variance in fp32 over the UNROUNDED sum y + bias + residual (PyTorch rounds to 16 bits
+// after the bias and again after the residual add).
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void add_ln_kernel(const uint2* __restrict__ y, const uint2* __restrict__ bias, const uint2* __restrict__ res,
+                                                     const uint2* __restrict__ gamma, const uint2* __restrict__ beta, float eps, long long rows,
+                                                     int d4, uint2* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    float v[VPL][4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 64 + lane;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.0f;
+        if (i < d4) {
+            const uint2 a = y[row * d4 + i];
+            float f[4];
+            enc_unpack2<DT>(a.x, f[0], f[1]);
+            enc_unpack2<DT>(a.y, f[2], f[3]);
+            if (bias) {
+                const uint2 bb = bias[i];
+                float t[4];
+                enc_unpack2<DT>(bb.x, t[0], t[1]);
+                enc_unpack2<DT>(bb.y, t[2], t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] += t[e];
+            }
+            if (res) {
+                const uint2 rr = res[row * d4 + i];
+                float t[4];
+                enc_unpack2<DT>(rr.x, t[0], t[1]);
+                enc_unpack2<DT>(rr.y, t[2], t[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) f[e] += t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = f[e]; sum += f[e]; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv_d = 1.0f / (float)(4 * d4);
+    const float mean = sum * inv_d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+        if (j * 64 + lane < d4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float t = v[j][e] - mean; sq = fmaf(t, t, sq); }
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq * inv_d + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 64 + lane;
+        if (i < d4) {
+            const uint2 gg = gamma[i], be = beta[i];
+            float gm[4], bt[4];
+            enc_unpack2<DT>(gg.x, gm[0], gm[1]);
+            enc_unpack2<DT>(gg.y, gm[2], gm[3]);
+            enc_unpack2<DT>(be.x, bt[0], bt[1]);
+            enc_unpack2<DT>(be.y, bt[2], bt[3]);
+            uint2 w;
+            w.x = enc_pack2<DT>(fmaf((v[j][0] - mean) * rstd, gm[0], bt[0]), fmaf((v[j][1] - mean) * rstd, gm[1], bt[1]));
+            w.y = enc_pack2<DT>(fmaf((v[j][2] - mean) * rstd, gm[2], bt[2]), fmaf((v[j][3] - mean) * rstd, gm[3], bt[3]));
+            out[row * d4 + i] = w;
+        }
+    }
+}
+
+template <int DT>
+static hipError_t launch_add_ln(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, long long rows,
+                                int d, void* out, hipStream_t s) {
+    const int d4 = d / 4, vpl = (d4 + 63) / 64;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define ENC_LN(V)                                                                                                                     \
+    hipLaunchKernelGGL((add_ln_kernel<DT, V>), grid, block, 0, s, reinterpret_cast<const uint2*>(y), reinterpret_cast<const uint2*>(bias), \
+                       reinterpret_cast<const uint2*>(res), reinterpret_cast<const uint2*>(gamma), reinterpret_cast<const uint2*>(beta), eps, \
+                       rows, d4, reinterpret_cast<uint2*>(out))
+    switch (vpl) {
+        case 1: ENC_LN(1); break;
+        case 2: ENC_LN(2); break;
+        case 3: ENC_LN(3); break;
+        case 4: ENC_LN(4); break;
+        case 5: case 6: ENC_LN(6); break;
+        case 7: case 8: ENC_LN(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef ENC_LN
+    return hipGetLastError();
+}
+
+hipError_t cmr_launch_add_layernorm(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, long long rows,
+                                    int d, int dtype, void* out, hipStream_t s) {
+    if (dtype == CMR_DT_BF16) return launch_add_ln<CMR_DT_BF16>(y, bias, res, gamma, beta, eps, rows, d, out, s);
+    return launch_add_ln<CMR_DT_F16>(y, bias, res, gamma, beta, eps, rows, d, out, s);
+}

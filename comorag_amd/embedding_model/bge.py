@@ -1,6 +1,7 @@
 """HipBGEEmbeddingModel — drop-in for BGEEmbeddingModel (src/comorag/embedding_model/BGEEmbedding.py).
 
-tokenise (HF tokenizers, host threads) → encoder forward (PyTorch-ROCm) → fused masked mean-pool +
+tokenise (HF tokenizers, host threads) → encoder forward (PyTorch-ROCm GEMMs; for 16-bit BERT encoders the attention and
+the bias + residual + LayerNorm stages are HIP kernels, fused_bert.py) → fused masked mean-pool +
 L2-normalise as ONE HIP kernel pair on the encoder's output tensor (`cmr_pool_l2norm`; replaces
 `mean_pooling` :15-28 and `F.normalize` :126-127).  Call surface, argument handling and quirks follow
 the reference:
@@ -105,6 +106,18 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self.embedding_model = model.to(self.device) if tdt is None else model.to(self.device, dtype=tdt)
         self.embedding_model.eval()
         self.embedding_dim = self.embedding_model.config.hidden_size
+        # 16-bit BERT encoders run their layers through fused_bert.FusedBertLayers (HIP attention and bias + residual +
+        # LayerNorm stages around PyTorch's GEMMs); anything else keeps the transformers forward.  `encoder_path` names it.
+        self._fused, self.encoder_path = None, "transformers"
+        if bool(cfg_get(self.global_config, "embedding_fused_encoder", True)):
+            from . import fused_bert
+            reason = fused_bert.why_not(self.embedding_model)
+            if reason is None and getattr(tokenizer, "padding_side", "right") != "right":
+                reason = "left-padding tokenizer"
+            if reason is None:
+                self._fused, self.encoder_path = fused_bert.FusedBertLayers(self.embedding_model), "hip-fused-layers"
+            else:
+                self.encoder_path = f"transformers ({reason})"
         self.max_positions = int(getattr(self.embedding_model.config, "max_position_embeddings", 1 << 30))
         import os
         # mini-batches of similar token count (sorted by length, results scattered back): a mini-batch is padded to ITS
@@ -147,8 +160,15 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         import torch
         with torch.no_grad():
             # pinned staging + non-blocking copies: the id tensors of mini-batch i+1 cross the link while batch i computes
+            lens = None
+            if self._fused is not None and not inputs["attention_mask"].is_cuda:
+                from .fused_bert import lens_of_mask
+                lens = lens_of_mask(inputs["attention_mask"].numpy())      # None unless every row is ones-then-zeros
             inputs = {k: (v.pin_memory() if not v.is_cuda else v).to(self.device, non_blocking=True) for k, v in inputs.items()}
-            hidden = self.embedding_model(**inputs).last_hidden_state
+            if lens is not None:
+                hidden = self._fused(inputs["input_ids"], lens, token_type_ids=inputs.get("token_type_ids"))
+            else:
+                hidden = self.embedding_model(**inputs).last_hidden_state
             return pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize)
 
     def _encode(self, prompts: Union[str, List[str]], **kwargs):

@@ -272,6 +272,24 @@ int32_t cmr_pool_l2norm(int32_t device_id, const void* hidden_dev, int32_t hidde
                         const int64_t* mask_dev, int32_t b, int32_t l, int32_t d, int32_t normalize,
                         float* out_dev, void* stream);
 
+/* ---- encoder layer pieces -----------------------------------------------------------------
+ * The two non-GEMM stages of a BERT layer inside `self.embedding_model(**inputs)` (embedding_model/BGEEmbedding.py:119; the
+ * GEMMs stay PyTorch-ROCm / hipBLASLt as north_star prescribes).  Both take device pointers of 16-bit tensors (dtype =
+ * CMR_BF16 or CMR_F16) and run on `stream`.
+ *
+ * cmr_encoder_attention: out[b*l, hidden] = softmax(Q K^T / sqrt(head_dim), keys >= lens[s] masked) V per sequence and head,
+ *   with Q | K | V the three hidden-wide column groups of ONE packed projection qkv_dev[b*l, 3*hidden] (hidden = n_heads *
+ *   head_dim, head h = columns h*head_dim.. of its group); lens_dev[b] int32 = real tokens of each right-padded sequence
+ *   (transformers' BertSelfAttention + its additive mask).  head_dim must be 64.  Rows >= lens[s] of out are unspecified
+ *   finite values (zeros where a whole 128-row block is padding): the pooling mask drops them.
+ * cmr_encoder_add_layernorm: out = LayerNorm(y + bias + residual) * gamma + beta over rows of d elements, fp32 statistics
+ *   (BertSelfOutput / BertOutput after their dense GEMM); bias_dev / residual_dev may be NULL.                              */
+int32_t cmr_encoder_attention(int32_t device_id, const void* qkv_dev, int32_t dtype, const int32_t* lens_dev,
+                              int32_t b, int32_t l, int32_t n_heads, int32_t head_dim, void* out_dev, void* stream);
+int32_t cmr_encoder_add_layernorm(int32_t device_id, const void* y_dev, const void* bias_dev,
+                                  const void* residual_dev, const void* gamma_dev, const void* beta_dev,
+                                  float eps, int64_t rows, int32_t d, int32_t dtype, void* out_dev, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------------
  * HIP-event timing of the dominant kernel (the corpus scan) on the stream it is launched on.
  * enable → run searches → collect returns launches, summed kernel ms and the algorithmic bytes

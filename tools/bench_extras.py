@@ -125,23 +125,45 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
     for i in range(0, n_chunks, batch):
         em._tokenize(chunks[i:i + batch], 512)
     dt_tok = time.perf_counter() - t0
-    # forward + pool alone
-    inp = {k: v.to(device) for k, v in em._tokenize(chunks[:batch], 512).items()}
+    # forward + pool alone: the path batch_encode runs (fused_bert.FusedBertLayers for 16-bit BERT encoders), and the transformers
+    # forward of the same model beside it
+    host_inp = em._tokenize(chunks[:batch], 512)
+    inp = {k: v.to(device) for k, v in host_inp.items()}
     tokens = int(inp["input_ids"].shape[1])
-    with torch.no_grad():
+    lens = host_inp["attention_mask"].numpy().sum(1).astype(np.int32)
+    product = (lambda: em._fused(inp["input_ids"], lens, token_type_ids=inp.get("token_type_ids"))) if em._fused is not None else None
+    plain = lambda: em.embedding_model(**inp).last_hidden_state
+
+    def timed(fn, reps):
         for _ in range(2):
-            hidden = em.embedding_model(**inp).last_hidden_state
+            out_ = fn()
         torch.cuda.synchronize(device)
-        reps = 6
-        t0 = time.perf_counter()
+        t0_ = time.perf_counter()
         for _ in range(reps):
-            hidden = em.embedding_model(**inp).last_hidden_state
-        torch.cuda.synchronize(device); dt_fwd = (time.perf_counter() - t0) / reps
-        pool_l2norm(hidden, inp["attention_mask"]); torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(20):
-            pool_l2norm(hidden, inp["attention_mask"])
-        torch.cuda.synchronize(device); dt_pool = (time.perf_counter() - t0) / 20
+            out_ = fn()
+        torch.cuda.synchronize(device)
+        return (time.perf_counter() - t0_) / reps, out_
+
+    stages = {}
+    with torch.no_grad():
+        dt_plain, hidden = timed(plain, 6)
+        dt_fwd = dt_plain
+        if product is not None:
+            dt_fwd, hidden = timed(product, 6)
+            fz = em._fused
+            T = batch * tokens
+            qkv = torch.randn((T, 3 * fz.hidden), device=device).to(fz.dtype)
+            lens_dev = torch.from_numpy(lens).to(device)
+            dt_att, ctx = timed(lambda: fz.attention(qkv, lens_dev, batch, tokens), 20)
+            lyr = fz.layers[0]
+            dt_ln, _ = timed(lambda: fz.add_layernorm(ctx, lyr[3], ctx, lyr[4], lyr[5]), 20)
+            att_flops = 4.0 * float((lens.astype(np.float64) ** 2).sum()) * fz.hidden
+            stages = {"attention_us_per_layer": dt_att * 1e6, "attention_TFLOPs": att_flops / dt_att / 1e12,
+                      "attention_frac_of_2500TF": att_flops / dt_att / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                      "add_layernorm_us": dt_ln * 1e6, "add_layernorm_GBps": 3.0 * T * fz.hidden * 2 / dt_ln / 1e9,
+                      "add_layernorm_frac_of_8TBps": 3.0 * T * fz.hidden * 2 / dt_ln / 1e9 / HBM_PEAK_GBS,
+                      "transformers_forward_only_chunks_per_s": batch / dt_plain}
+        dt_pool, _ = timed(lambda: pool_l2norm(hidden, inp["attention_mask"]), 20)
     h, L = em.embedding_model.config.hidden_size, em.embedding_model.config.num_hidden_layers
     flops = bert_flops_per_chunk(h, L, tokens)
     fwd_rate = batch / dt_fwd
@@ -151,8 +173,9 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
            "tokenizer_only_chunks_per_s": n_chunks / dt_tok, "forward_only_chunks_per_s": fwd_rate,
            "pool_l2norm_us_per_batch": dt_pool * 1e6, "pool_GBps": pool_bytes / dt_pool / 1e9, "pool_frac_of_8TBps": pool_bytes / dt_pool / 1e9 / HBM_PEAK_GBS,
            "gflop_per_chunk": flops / 1e9, "forward_TFLOPs": fwd_rate * flops / 1e12, "frac": fwd_rate * flops / 1e12 / MFMA_BF16_PEAK_TFLOPS if dtype != "auto" else fwd_rate * flops / 1e12 / F32_PEAK_TFLOPS,
-           "frac_of": ("2.5 PFLOP/s dense bf16/fp16 MFMA" if dtype != "auto" else "157 TFLOP/s fp32") + " for the forward alone (PyTorch-ROCm, by north_star's design); end-to-end = tokenizer overlapped with forward + HIP pool",
-           "end_to_end_over_forward_only": (n_chunks / dt_e2e) / fwd_rate, "tokenizer_processes": tok_processes}
+           "frac_of": ("2.5 PFLOP/s dense bf16/fp16 MFMA" if dtype != "auto" else "157 TFLOP/s fp32") + " for the forward alone (GEMMs: PyTorch-ROCm / hipBLASLt, by north_star's design; attention and bias + residual + LayerNorm: HIP for 16-bit BERT encoders); end-to-end = tokenizer overlapped with forward + HIP pool",
+           "end_to_end_over_forward_only": (n_chunks / dt_e2e) / fwd_rate, "tokenizer_processes": tok_processes,
+           "encoder_path": em.encoder_path, **stages}
     return res, em
 
 
