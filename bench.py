@@ -520,8 +520,8 @@ def main():
         from tools import bench_extras as bx
         rows = (("config4_probe_loop", lambda: bx.config4_probe_loop(torch, device, dim=args.dim, dtype=args.dtype, rows0=min(2_000_000, max(args.rows, 200_000)), k=args.k)),
                 ("corpus_embed", lambda: bx.encode_breakdown(torch, device, "base", "auto", 128)[0]),
-                ("corpus_embed_bf16", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 256)[0]),
-                ("corpus_embed_bf16_tokenizer_processes", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 256, tok_processes=4)[0]),
+                ("corpus_embed_bf16", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 1024)[0]),
+                ("corpus_embed_bf16_tokenizer_processes", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 1024, tok_processes=4)[0]),
                 ("config5_bge_large_fp16_encode_search_rescore", lambda: bx.config5_encode_search_rescore(torch, device)),
                 ("f1_synonymy_selfjoin", lambda: bx.f1_selfjoin(torch, device, dim=args.dim)),
                 ("f4_dpr_seeded_ppr", lambda: bx.f4_ppr(torch, device)))

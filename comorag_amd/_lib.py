@@ -78,6 +78,7 @@ SIGNATURES = {
     "cmr_comm_info": (_i32, [_p, _P(_i32), _P(_i32), _P(_i32)]),
     "cmr_comm_allgather_merge": (_i32, [_p, _p, _p, _i32, _i32, _p, _p, _p]),
     "cmr_pool_l2norm": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmr_encoder_embed_layernorm": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_encoder_attention": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_encoder_add_layernorm": (_i32, [_i32, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i32, _p, _p]),
     "cmr_profile_enable": (_i32, [_p, _i32]),

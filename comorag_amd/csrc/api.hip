@@ -1613,6 +1613,24 @@ int32_t cmr_encoder_add_layernorm(int32_t device_id, const void* y_dev, const vo
     return CMR_OK;
 }
 
+int32_t cmr_encoder_embed_layernorm(int32_t device_id, const int64_t* ids_dev, const int64_t* token_type_dev, const void* word_dev, const void* pos_dev,
+                                    const void* type_dev, const void* gamma_dev, const void* beta_dev, float eps, int64_t rows, int32_t l, int32_t d,
+                                    int32_t vocab, int32_t n_positions, int32_t n_types, int32_t dtype, void* out_dev, void* stream) {
+    if (!ids_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (rows <= 0 || l <= 0 || d <= 0 || d % 4 || d > 2048) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: rows, l > 0, d a multiple of 4, d <= 2048");
+    if (vocab <= 0 || n_positions <= 0 || n_types <= 0) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: empty embedding table");
+    if (dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: dtype must be bf16 or f16");
+    if (((uintptr_t)word_dev | (uintptr_t)pos_dev | (uintptr_t)type_dev | (uintptr_t)gamma_dev | (uintptr_t)beta_dev | (uintptr_t)out_dev) & 7)
+        return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: buffers must be 8-byte aligned");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    HIP_TRY(cmr_launch_embed_layernorm((const long long*)ids_dev, (const long long*)token_type_dev, word_dev, pos_dev, type_dev, gamma_dev, beta_dev, eps,
+                                       rows, l, d, vocab, n_positions, n_types, dtype, out_dev, (hipStream_t)stream));
+    return CMR_OK;
+}
+
 int32_t cmr_profile_enable(cmr_index_t* idx, int32_t on) {
     if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
     std::lock_guard<std::mutex> g(idx->prof_mu);

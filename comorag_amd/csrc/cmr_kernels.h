@@ -111,5 +111,8 @@ int cmr_pool_splits(int b, int l, int d);
 // encoder layer pieces (encoder_kernels.hip): masked attention over a packed [b*L, 3*hidden] projection (head width 64, 16-bit),
 // LayerNorm(y + bias + residual) (16-bit, d % 4 == 0, d <= 2048; bias / residual may be NULL)
 hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int b, int L, int n_heads, void* out, hipStream_t s);
+hipError_t cmr_launch_embed_layernorm(const long long* ids, const long long* tt, const void* word, const void* pos, const void* type,
+                                      const void* gamma, const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos,
+                                      int n_types, int dtype, void* out, hipStream_t s);
 hipError_t cmr_launch_add_layernorm(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps,
                                     long long rows, int d, int dtype, void* out, hipStream_t s);

@@ -7,6 +7,7 @@
 //   add_ln_kernel     LayerNorm(y + bias + residual) * gamma + beta, one wave per token: BertSelfOutput / BertOutput minus
 //                     their GEMM (dense bias add, residual add and LayerNorm are three kernels and five passes over the
 //                     activations in PyTorch; here one read of y and the residual, one write).
+//   embed_ln_kernel   BertEmbeddings: the word / position / token-type gathers, their sum and the LayerNorm in one pass.
 //
 // Attention layout.  Q, K, V are column slices of ONE packed projection output qkv[b*L, 3*hidden] (the host side multiplies by
 // the concatenated query/key/value weights once): head h reads columns h*64 (Q), hidden + h*64 (K), 2*hidden + h*64 (V).
@@ -234,44 +235,11 @@ hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int
 // One wave per token row, d = 4 * d4 elements, lane holds vectors lane, lane + 64, ... (8-byte loads: a wave instruction reads
 // 512 contiguous bytes).  Sum, mean and variance in fp32 over the UNROUNDED sum y + bias + residual (PyTorch rounds to 16 bits
 // after the bias and again after the residual add).
+// v[VPL][4] = the lane's elements of one row (vector i = j*64 + lane, valid while i < d4): mean / variance over the wave, then
+// (v - mean) * rstd * gamma + beta, rounded once, written as 8-byte vectors
 template <int DT, int VPL>
-__global__ __launch_bounds__(256) void add_ln_kernel(const uint2* __restrict__ y, const uint2* __restrict__ bias, const uint2* __restrict__ res,
-                                                     const uint2* __restrict__ gamma, const uint2* __restrict__ beta, float eps, long long rows,
-                                                     int d4, uint2* __restrict__ out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long row = (long long)blockIdx.x * 4 + wave;
-    if (row >= rows) return;
-    float v[VPL][4];
-    float sum = 0.0f;
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-        const int i = j * 64 + lane;
-        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.0f;
-        if (i < d4) {
-            const uint2 a = y[row * d4 + i];
-            float f[4];
-            enc_unpack2<DT>(a.x, f[0], f[1]);
-            enc_unpack2<DT>(a.y, f[2], f[3]);
-            if (bias) {
-                const uint2 bb = bias[i];
-                float t[4];
-                enc_unpack2<DT>(bb.x, t[0], t[1]);
-                enc_unpack2<DT>(bb.y, t[2], t[3]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] += t[e];
-            }
-            if (res) {
-                const uint2 rr = res[row * d4 + i];
-                float t[4];
-                enc_unpack2<DT>(rr.x, t[0], t[1]);
-                enc_unpack2<DT>(rr.y, t[2], t[3]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) f[e] += t[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[j][e] = f[e]; sum += f[e]; }
-        }
-    }
+__device__ __forceinline__ void enc_ln_store(float (&v)[VPL][4], float sum, int lane, int d4, const uint2* __restrict__ gamma,
+                                             const uint2* __restrict__ beta, float eps, uint2* __restrict__ out_row) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
     const float inv_d = 1.0f / (float)(4 * d4);
@@ -299,9 +267,70 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const uint2* __restrict__ y
             uint2 w;
             w.x = enc_pack2<DT>(fmaf((v[j][0] - mean) * rstd, gm[0], bt[0]), fmaf((v[j][1] - mean) * rstd, gm[1], bt[1]));
             w.y = enc_pack2<DT>(fmaf((v[j][2] - mean) * rstd, gm[2], bt[2]), fmaf((v[j][3] - mean) * rstd, gm[3], bt[3]));
-            out[row * d4 + i] = w;
+            out_row[i] = w;
         }
     }
+}
+template <int DT> __device__ __forceinline__ void enc_acc4(float (&f)[4], uint2 a) {
+    float t[4];
+    enc_unpack2<DT>(a.x, t[0], t[1]);
+    enc_unpack2<DT>(a.y, t[2], t[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] += t[e];
+}
+
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void add_ln_kernel(const uint2* __restrict__ y, const uint2* __restrict__ bias, const uint2* __restrict__ res,
+                                                     const uint2* __restrict__ gamma, const uint2* __restrict__ beta, float eps, long long rows,
+                                                     int d4, uint2* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    float v[VPL][4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 64 + lane;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.0f;
+        if (i < d4) {
+            enc_acc4<DT>(v[j], y[row * d4 + i]);
+            if (bias) enc_acc4<DT>(v[j], bias[i]);
+            if (res) enc_acc4<DT>(v[j], res[row * d4 + i]);
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    enc_ln_store<DT, VPL>(v, sum, lane, d4, gamma, beta, eps, out + row * d4);
+}
+
+// BertEmbeddings: LayerNorm(word[ids[t]] + position[t mod L] + token_type[tt[t]]), one wave per token (tt == NULL: type 0).
+// Ids outside the tables are clamped into them (PyTorch's gather would fault the device instead).
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const long long* __restrict__ ids, const long long* __restrict__ tt,
+                                                       const uint2* __restrict__ word, const uint2* __restrict__ pos, const uint2* __restrict__ type,
+                                                       const uint2* __restrict__ gamma, const uint2* __restrict__ beta, float eps, long long rows,
+                                                       int L, int d4, int vocab, int n_pos, int n_types, uint2* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    long long id = ids[row], ty = tt ? tt[row] : 0;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    ty = ty < 0 ? 0 : (ty >= n_types ? n_types - 1 : ty);
+    int p = (int)(row % L);
+    p = p >= n_pos ? n_pos - 1 : p;
+    float v[VPL][4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 64 + lane;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.0f;
+        if (i < d4) {
+            enc_acc4<DT>(v[j], word[id * d4 + i]);
+            enc_acc4<DT>(v[j], pos[(long long)p * d4 + i]);
+            enc_acc4<DT>(v[j], type[ty * d4 + i]);
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    enc_ln_store<DT, VPL>(v, sum, lane, d4, gamma, beta, eps, out + row * d4);
 }
 
 template <int DT>
@@ -324,6 +353,36 @@ static hipError_t launch_add_ln(const void* y, const void* bias, const void* res
     }
 #undef ENC_LN
     return hipGetLastError();
+}
+
+template <int DT>
+static hipError_t launch_embed_ln(const long long* ids, const long long* tt, const void* word, const void* pos, const void* type, const void* gamma,
+                                  const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos, int n_types, void* out,
+                                  hipStream_t s) {
+    const int d4 = d / 4, vpl = (d4 + 63) / 64;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define ENC_EMB(V)                                                                                                                       \
+    hipLaunchKernelGGL((embed_ln_kernel<DT, V>), grid, block, 0, s, ids, tt, reinterpret_cast<const uint2*>(word), reinterpret_cast<const uint2*>(pos), \
+                       reinterpret_cast<const uint2*>(type), reinterpret_cast<const uint2*>(gamma), reinterpret_cast<const uint2*>(beta), eps, rows, \
+                       L, d4, vocab, n_pos, n_types, reinterpret_cast<uint2*>(out))
+    switch (vpl) {
+        case 1: ENC_EMB(1); break;
+        case 2: ENC_EMB(2); break;
+        case 3: ENC_EMB(3); break;
+        case 4: ENC_EMB(4); break;
+        case 5: case 6: ENC_EMB(6); break;
+        case 7: case 8: ENC_EMB(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef ENC_EMB
+    return hipGetLastError();
+}
+
+hipError_t cmr_launch_embed_layernorm(const long long* ids, const long long* tt, const void* word, const void* pos, const void* type,
+                                      const void* gamma, const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos,
+                                      int n_types, int dtype, void* out, hipStream_t s) {
+    if (dtype == CMR_DT_BF16) return launch_embed_ln<CMR_DT_BF16>(ids, tt, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, n_types, out, s);
+    return launch_embed_ln<CMR_DT_F16>(ids, tt, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, n_types, out, s);
 }
 
 hipError_t cmr_launch_add_layernorm(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, long long rows,

@@ -8,9 +8,10 @@ mask, the output GEMM, bias / residual adds, LayerNorm, the FFN GEMMs and GELU. 
     x    = cmr_encoder_add_layernorm(ctx @ Wo^T, bo, x)       HIP: dense bias + residual + LayerNorm in one pass
     x    = cmr_encoder_add_layernorm(gelu(x @ W1^T + b1) @ W2^T, b2, x)
 
-seven host calls per layer, so the thread that launches the forward leaves the interpreter lock to the tokenizer threads sooner.
-The weights are the loaded model's own tensors (query / key / value concatenated once); embeddings stay the model's
-`embeddings` module.  Results equal the transformers forward up to 16-bit rounding (the fused LayerNorm rounds once instead of
+seven host calls per layer — and ONE per forward once a mini-batch shape has been captured as a hipGraph (`graphs`) — so the
+thread that launches the forward leaves the interpreter lock to the tokenizer threads.
+The weights are the loaded model's own tensors (query / key / value concatenated once); the embedding gathers, their sum and
+LayerNorm are one HIP kernel (cmr_encoder_embed_layernorm).  Results equal the transformers forward up to 16-bit rounding (the fused LayerNorm rounds once instead of
 three times): tests/test_encoder_fused_gpu.py compares both with the fp32 oracle.
 
 Used when `why_not(model)` is None: BERT architecture, absolute positions, exact GELU, 64-wide heads, bf16 / fp16 weights; any
@@ -32,7 +33,8 @@ def why_not(model) -> Optional[str]:
     cfg = getattr(model, "config", None)
     if cfg is None or getattr(cfg, "model_type", "") != "bert":
         return "not a BERT encoder"
-    if not (hasattr(model, "embeddings") and hasattr(model, "encoder") and hasattr(model.encoder, "layer")):
+    if not (hasattr(model, "embeddings") and hasattr(model, "encoder") and hasattr(model.encoder, "layer")
+            and all(hasattr(model.embeddings, n) for n in ("word_embeddings", "position_embeddings", "token_type_embeddings", "LayerNorm"))):
         return "unexpected module layout"
     if getattr(cfg, "position_embedding_type", None) not in (None, "absolute"):
         return "relative position embeddings"
@@ -62,7 +64,7 @@ def lens_of_mask(mask: np.ndarray) -> Optional[np.ndarray]:
 
 
 class FusedBertLayers:
-    def __init__(self, model):
+    def __init__(self, model, graphs: int = 0):
         import torch
         reason = why_not(model)
         if reason is not None:
@@ -73,6 +75,12 @@ class FusedBertLayers:
         self.dtype = next(model.parameters()).dtype
         self.cmr_dtype = L.CMR_BF16 if self.dtype == torch.bfloat16 else L.CMR_F16
         self.device = next(model.parameters()).device
+        emb = model.embeddings
+        self.emb = tuple(t.detach().contiguous() for t in (emb.word_embeddings.weight, emb.position_embeddings.weight,
+                                                           emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias))
+        import threading
+        self.graphs = int(graphs)                    # mini-batch shapes kept as captured hipGraphs (0: every forward is launched eagerly)
+        self._graphs, self._seen, self._glock = {}, {}, threading.Lock()
         self.layers = []
         with torch.no_grad():
             for lyr in model.encoder.layer:
@@ -94,6 +102,23 @@ class FusedBertLayers:
                                               b, l, self.n_heads, 64, C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
+    def embed(self, input_ids, token_type_ids=None, stream: Optional[int] = None):
+        """BertEmbeddings of a [b, l] id tensor → [b*l, hidden]."""
+        import torch
+        b, l = input_ids.shape
+        word, pos, typ, gamma, beta = self.emb
+        ids = input_ids.contiguous()
+        tt = token_type_ids.contiguous() if token_type_ids is not None else None
+        out = torch.empty((b * l, self.hidden), dtype=word.dtype, device=ids.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(ids.device).cuda_stream
+        L.check(L.lib().cmr_encoder_embed_layernorm(ids.device.index or 0, C.c_void_p(ids.data_ptr()), C.c_void_p(tt.data_ptr() if tt is not None else 0),
+                                                    C.c_void_p(word.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                                    C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), self.eps, b * l, l, self.hidden,
+                                                    word.shape[0], pos.shape[0], typ.shape[0], self.cmr_dtype, C.c_void_p(out.data_ptr()),
+                                                    C.c_void_p(stream)))
+        return out
+
     def add_layernorm(self, y, bias, residual, gamma, beta, stream: Optional[int] = None):
         import torch
         out = torch.empty_like(y)
@@ -106,21 +131,67 @@ class FusedBertLayers:
         return out
 
     # ------------------------------------------------------------------ forward
-    def __call__(self, input_ids, lens: np.ndarray, token_type_ids=None):
-        """input_ids [b, l] int64 on the GPU (right-padded), lens[b] real token counts (host) → last hidden state [b, l, hidden]."""
+    def _stack(self, input_ids, lens_dev, token_type_ids):
+        """Embeddings + every layer on torch's current stream; all arguments on the GPU."""
         import torch
         import torch.nn.functional as F
         b, l = input_ids.shape
+        stream = torch.cuda.current_stream(input_ids.device).cuda_stream
+        x = self.embed(input_ids, token_type_ids, stream)
+        for (wqkv, bqkv, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2) in self.layers:
+            qkv = F.linear(x, wqkv, bqkv)
+            ctx = self.attention(qkv, lens_dev, b, l, stream)
+            x = self.add_layernorm(F.linear(ctx, wo), bo, x, g1, be1, stream)
+            h = F.gelu(F.linear(x, w1, b1))
+            x = self.add_layernorm(F.linear(h, w2), b2, x, g2, be2, stream)
+        return x.view(b, l, self.hidden)
+
+    def __call__(self, input_ids, lens: np.ndarray, token_type_ids=None, consume=None):
+        """input_ids [b, l] int64 on the GPU (right-padded), lens[b] real token counts (host) → last hidden state [b, l, hidden];
+        with `consume`, returns consume(hidden) instead.
+
+        A mini-batch shape seen before runs as ONE captured hipGraph (`graphs` > 0: up to that many shapes are kept, captured at
+        a shape's second occurrence): ~100 launches and as many interpreter round trips become one, which is most of a short
+        query's encode time and leaves the interpreter lock to the tokenizer threads during corpus encodes.  A graph's inputs and
+        output are its own static buffers, so replays are serialised by a lock and `consume` (the pooling kernel's launch) runs
+        under it: the next replay is stream-ordered behind the reader of this one's output."""
+        import torch
+        b, l = input_ids.shape
         with torch.no_grad():
-            lens_dev = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).to(input_ids.device, non_blocking=True)
-            x = self.model.embeddings(input_ids=input_ids, token_type_ids=token_type_ids).reshape(b * l, self.hidden)
-            if not x.is_contiguous():
-                x = x.contiguous()
-            stream = torch.cuda.current_stream(input_ids.device).cuda_stream
-            for (wqkv, bqkv, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2) in self.layers:
-                qkv = F.linear(x, wqkv, bqkv)
-                ctx = self.attention(qkv, lens_dev, b, l, stream)
-                x = self.add_layernorm(F.linear(ctx, wo), bo, x, g1, be1, stream)
-                h = F.gelu(F.linear(x, w1, b1))
-                x = self.add_layernorm(F.linear(h, w2), b2, x, g2, be2, stream)
-            return x.view(b, l, self.hidden)
+            # (pinned: a copy from pageable memory makes the host wait for everything queued on the stream before it)
+            lens_host = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).pin_memory()
+            key = (b, l, token_type_ids is not None)
+            if self.graphs > 0:
+                with self._glock:
+                    ent = self._graphs.get(key)
+                    if ent is None:
+                        seen = self._seen[key] = self._seen.get(key, 0) + 1
+                        if seen >= 2 and len(self._graphs) < self.graphs:
+                            ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None)
+                    if ent is not None:
+                        ent["ids"].copy_(input_ids, non_blocking=True)
+                        ent["lens"].copy_(lens_host, non_blocking=True)
+                        if token_type_ids is not None:
+                            ent["tt"].copy_(token_type_ids, non_blocking=True)
+                        ent["graph"].replay()
+                        return consume(ent["hidden"]) if consume is not None else ent["hidden"].clone()
+            hidden = self._stack(input_ids, lens_host.to(input_ids.device, non_blocking=True), token_type_ids)
+            return consume(hidden) if consume is not None else hidden
+
+    def _capture(self, b: int, l: int, has_tt: bool):
+        """Static buffers + one eager pass on a side stream (allocator and GEMM-heuristic warm-up) + the captured pass."""
+        import torch
+        dev = self.device
+        ent = {"ids": torch.zeros((b, l), dtype=torch.int64, device=dev), "lens": torch.ones((b,), dtype=torch.int32, device=dev),
+               "tt": torch.zeros((b, l), dtype=torch.int64, device=dev) if has_tt else None}
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._stack(ent["ids"], ent["lens"], ent["tt"])
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"])
+        ent["graph"] = graph
+        return ent

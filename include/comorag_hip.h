@@ -282,8 +282,16 @@ int32_t cmr_pool_l2norm(int32_t device_id, const void* hidden_dev, int32_t hidde
  *   head_dim, head h = columns h*head_dim.. of its group); lens_dev[b] int32 = real tokens of each right-padded sequence
  *   (transformers' BertSelfAttention + its additive mask).  head_dim must be 64.  Rows >= lens[s] of out are unspecified
  *   finite values (zeros where a whole 128-row block is padding): the pooling mask drops them.
+ * cmr_encoder_embed_layernorm: out[t] = LayerNorm(word[ids[t]] + position[t mod l] + token_type[tt[t]]) for the rows = b*l tokens
+ *   of a [b, l] mini-batch (transformers' BertEmbeddings with default position ids; token_type_dev NULL = type 0; ids outside a
+ *   table are clamped into it).
  * cmr_encoder_add_layernorm: out = LayerNorm(y + bias + residual) * gamma + beta over rows of d elements, fp32 statistics
  *   (BertSelfOutput / BertOutput after their dense GEMM); bias_dev / residual_dev may be NULL.                              */
+int32_t cmr_encoder_embed_layernorm(int32_t device_id, const int64_t* ids_dev, const int64_t* token_type_dev,
+                                    const void* word_dev, const void* pos_dev, const void* type_dev,
+                                    const void* gamma_dev, const void* beta_dev, float eps, int64_t rows, int32_t l,
+                                    int32_t d, int32_t vocab, int32_t n_positions, int32_t n_types, int32_t dtype,
+                                    void* out_dev, void* stream);
 int32_t cmr_encoder_attention(int32_t device_id, const void* qkv_dev, int32_t dtype, const int32_t* lens_dev,
                               int32_t b, int32_t l, int32_t n_heads, int32_t head_dim, void* out_dev, void* stream);
 int32_t cmr_encoder_add_layernorm(int32_t device_id, const void* y_dev, const void* bias_dev,

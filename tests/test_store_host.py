@@ -255,3 +255,26 @@ def test_tokenizer_worker_process_returns_what_the_in_process_tokenizer_returns(
     with mp.get_context("spawn").Pool(1, initializer=_tokworker.init, initargs=(tok.backend_tokenizer.to_str(),)) as pool:
         got = pool.apply(_tokworker.ragged, (texts, 512))
         assert as_lists(got) == want and all(a.dtype == np.int32 for a in got)
+
+
+def test_private_backend_copies_equal_the_tokenizer_call_under_concurrency():
+    """HipBGEEmbeddingModel tokenises through private, never-reconfigured copies of the Rust backend (one per max_length):
+    same ids / padded tensors as `tokenizer(prompts, padding=..., truncation=True, max_length=...)` (BGEEmbedding.py:112-117),
+    also when threads ask for different lengths at the same time (the shared backend is re-configured per call and races)."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel, tokenize_batch, tokenize_ragged
+    from tools.synthetic import synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer()
+    texts = synthetic_chunks(words, 12, tokens_per_chunk=560) + ["midnight", "the prince and the bird", ""]
+    em = HipBGEEmbeddingModel.__new__(HipBGEEmbeddingModel)                 # host-side methods only: no GPU in this tier
+    em.tokenizer, em._fast_tok, em._bt_copies, em._bt_lock, em.max_positions = tok, True, {}, threading.Lock(), 512
+    want = {ml: (tokenize_ragged(tok, texts, ml), tokenize_batch(tok, texts, ml)) for ml in (512, 64, 7)}
+
+    def one(ml):
+        rag, pad = em._ragged(texts, ml), em._tokenize(texts, ml)
+        return rag == want[ml][0] and set(pad) == set(want[ml][1]) and all(
+            pad[k].dtype == want[ml][1][k].dtype and (pad[k].numpy() == want[ml][1][k].numpy()).all() for k in pad)
+    with ThreadPoolExecutor(6) as ex:
+        assert all(ex.map(one, [512, 64, 7] * 8))
+    assert sorted(em._bt_copies) == [7, 64, 512]

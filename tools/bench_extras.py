@@ -119,7 +119,9 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
     chunks = synthetic_chunks(words, n_chunks, tokens_per_chunk=560)          # > 512 word pieces: every chunk is truncated to 512 positions
     em.batch_encode(chunks[:2 * batch])
     torch.cuda.synchronize(device)
+    em._trace = []
     t0 = time.perf_counter(); out = em.batch_encode(chunks); torch.cuda.synchronize(device); dt_e2e = time.perf_counter() - t0
+    trace, em._trace = em._trace, None
     # tokenizer alone
     t0 = time.perf_counter()
     for i in range(0, n_chunks, batch):
@@ -175,7 +177,9 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
            "gflop_per_chunk": flops / 1e9, "forward_TFLOPs": fwd_rate * flops / 1e12, "frac": fwd_rate * flops / 1e12 / MFMA_BF16_PEAK_TFLOPS if dtype != "auto" else fwd_rate * flops / 1e12 / F32_PEAK_TFLOPS,
            "frac_of": ("2.5 PFLOP/s dense bf16/fp16 MFMA" if dtype != "auto" else "157 TFLOP/s fp32") + " for the forward alone (GEMMs: PyTorch-ROCm / hipBLASLt, by north_star's design; attention and bias + residual + LayerNorm: HIP for 16-bit BERT encoders); end-to-end = tokenizer overlapped with forward + HIP pool",
            "end_to_end_over_forward_only": (n_chunks / dt_e2e) / fwd_rate, "tokenizer_processes": tok_processes,
-           "encoder_path": em.encoder_path, **stages}
+           "encoder_path": em.encoder_path, **stages,
+           "host_ms": {"end_to_end": dt_e2e * 1e3, "waiting_for_token_ids": sum(t[0] for t in trace) * 1e3,
+                       "padding_and_launching": sum(t[1] for t in trace) * 1e3, "windows": len(trace)}}
     return res, em
 
 
