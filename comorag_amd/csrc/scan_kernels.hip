@@ -477,11 +477,19 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 // W = gridDim.x.
 #define WIDE_WAVES 4
 #ifndef WIDE_GROUP
-#define WIDE_GROUP 16     // blocks per staged group
+#define WIDE_GROUP 16     // blocks per staged group where 24 does not divide a row's k-steps (1024-d: 64), and for the 8-wave variant
 #endif
 #ifndef WIDE4_NST
-#define WIDE4_NST 8       // stages of the LDS ring (4-wave kernel): WIDE4_NST x WIDE_GROUP KiB, one stage being refilled
+#define WIDE4_NST 8       // stages of the LDS ring at WIDE_GROUP (4-wave kernel): WIDE4_NST x WIDE_GROUP KiB, one stage being refilled
 #endif
+#ifndef WIDE_GROUP3
+#define WIDE_GROUP3 24    // blocks per staged group where 24 divides a row's k-steps (768-d: 48 = two groups, two barriers per panel
+#endif                    // instead of three: 3.907 -> 3.853 ms at 10 M rows, profiles/r3_measurements.md; 8-KiB groups cost +6 %)
+#ifndef WIDE4_NST3
+#define WIDE4_NST3 5      // stages of the ring at WIDE_GROUP3 (120 KiB; 6 stages with half the staging records measured no better)
+#endif
+constexpr int wide_group(int ks, int nw) { return (nw == 4 && ks % WIDE_GROUP3 == 0) ? WIDE_GROUP3 : WIDE_GROUP; }
+constexpr int wide_nst4(int ks) { return ks % WIDE_GROUP3 == 0 ? WIDE4_NST3 : WIDE4_NST; }
 #define WIDE_ADEPTH 8     // LDS read-ahead ring of a wave, in blocks (two quads: one in use, one landing)
 
 // Epilogue pieces of the wide kernel.  The wave's register file is full of query fragments, and hipcc's allocator
@@ -737,7 +745,7 @@ __device__ __forceinline__ void wide_compact(u64 need, int k, u64& tau_key, floa
 // the LDS's 256 B/clk ds_read_b128 rate at full MFMA rate, guide §LDS) and a 4-block read-ahead ring instead of 8.
 template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS, int ABL = 0, int NW = WIDE_WAVES>
 __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
-    constexpr int GRP = WIDE_GROUP, NST = NSTG, ADEPTH = NW == 8 ? 4 : WIDE_ADEPTH;
+    constexpr int GRP = wide_group(KS, NW), NST = NSTG, ADEPTH = NW == 8 ? 4 : WIDE_ADEPTH;
     constexpr int STG = NW == 8 ? WIDE8_STG : WIDE_STG;         // staging records per wave (LDS budget)
     static_assert(NW == 4 || (NW == 8 && NT == 1), "8 waves hold one tile each");
     static_assert(NW == 4 || (size_t)STG * 16 <= (size_t)(CAP + 2) * 8, "8-wave kernel: the staging records live in the compaction stage");
@@ -1081,14 +1089,14 @@ static WideCfg wide_cfg(int ks, int cap, int waves) {
 #ifdef CMR_WIDE8
         if (waves == 8) return {8, 1, cap > 128 ? WIDE8_NST - 1 : WIDE8_NST, WIDE8_STG, WIDE8_KLDS};
 #endif
-        return {4, 2, WIDE4_NST, WIDE_STG, 0};
+        return {4, 2, wide_nst4(48), WIDE_STG, 0};
     }
-    return {4, 1, WIDE4_NST, WIDE_STG, 0};
+    return {4, 1, wide_nst4(ks), WIDE_STG, 0};
 }
 
 size_t cmr_wide_lds_bytes(int ks, int cap, int waves) {
     const WideCfg c = wide_cfg(ks, cap, waves);
-    return (size_t)c.nst * WIDE_GROUP * 1024 + (size_t)c.nw * c.nt * 32 * 4 + (size_t)c.nw * (cap + 2) * 8 + (size_t)c.nw * c.nt * c.klds * 1024 +
+    return (size_t)c.nst * wide_group(ks, c.nw) * 1024 + (size_t)c.nw * c.nt * 32 * 4 + (size_t)c.nw * (cap + 2) * 8 + (size_t)c.nw * c.nt * c.klds * 1024 +
            (c.nw == 8 ? 0 : (size_t)c.nw * c.stg * 16) + c.nw * 4;
 }
 
@@ -1115,13 +1123,13 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipS
 #ifdef CMR_DEV_KNOBS
     // development builds: ablation kernels (results are wrong by design) behind the "wide_abl" option
     if (g.wide_abl && g.dtype == CMR_DT_BF16 && g.ks == 48 && g.cap == 128 && c.nw == 4) {
-        if (g.wide_abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 1>);
-        if (g.wide_abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 2>);
-        if (g.wide_abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 3>);
-        if (g.wide_abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 4>);
-        if (g.wide_abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 5>);
-        if (g.wide_abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 6>);
-        if (g.wide_abl == 7) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 0, 7>);
+        if (g.wide_abl == 1) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 1>);
+        if (g.wide_abl == 2) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 2>);
+        if (g.wide_abl == 3) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 3>);
+        if (g.wide_abl == 4) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 4>);
+        if (g.wide_abl == 5) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 5>);
+        if (g.wide_abl == 6) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 6>);
+        if (g.wide_abl == 7) return launch(scan_wide_kernel<CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 0, 7>);
     }
 #endif
 #if defined(CMR_DEV_KNOBS) && defined(CMR_WIDE8)
@@ -1133,14 +1141,14 @@ hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipS
     }
 #endif
 #define WCASE(DT, KSV, NTV, CAPV, NSTV, NWV) if (g.dtype == DT && g.ks == KSV && g.cap == CAPV && c.nw == NWV) return launch(scan_wide_kernel<DT, KSV, NTV, CAPV, NSTV, (NWV == 8 ? WIDE8_KLDS : 0), 0, NWV>);
-    WCASE(CMR_DT_BF16, 48, 2, 128, WIDE4_NST, 4) WCASE(CMR_DT_BF16, 48, 2, 256, WIDE4_NST, 4)
-    WCASE(CMR_DT_F16, 48, 2, 128, WIDE4_NST, 4) WCASE(CMR_DT_F16, 48, 2, 256, WIDE4_NST, 4)
+    WCASE(CMR_DT_BF16, 48, 2, 128, wide_nst4(48), 4) WCASE(CMR_DT_BF16, 48, 2, 256, wide_nst4(48), 4)
+    WCASE(CMR_DT_F16, 48, 2, 128, wide_nst4(48), 4) WCASE(CMR_DT_F16, 48, 2, 256, wide_nst4(48), 4)
 #ifdef CMR_WIDE8     // experimental: two waves per SIMD, one tile each (hipcc does not yet fit it into 256 registers without spills)
     WCASE(CMR_DT_BF16, 48, 1, 128, WIDE8_NST, 8) WCASE(CMR_DT_BF16, 48, 1, 256, WIDE8_NST - 1, 8)
     WCASE(CMR_DT_F16, 48, 1, 128, WIDE8_NST, 8) WCASE(CMR_DT_F16, 48, 1, 256, WIDE8_NST - 1, 8)
 #endif
-    WCASE(CMR_DT_BF16, 64, 1, 128, WIDE4_NST, 4) WCASE(CMR_DT_BF16, 64, 1, 256, WIDE4_NST, 4)
-    WCASE(CMR_DT_F16, 64, 1, 128, WIDE4_NST, 4) WCASE(CMR_DT_F16, 64, 1, 256, WIDE4_NST, 4)
+    WCASE(CMR_DT_BF16, 64, 1, 128, wide_nst4(64), 4) WCASE(CMR_DT_BF16, 64, 1, 256, wide_nst4(64), 4)
+    WCASE(CMR_DT_F16, 64, 1, 128, wide_nst4(64), 4) WCASE(CMR_DT_F16, 64, 1, 256, wide_nst4(64), 4)
 #undef WCASE
     return hipErrorInvalidValue;
 }

@@ -169,6 +169,10 @@ class FusedBertLayers:
                         if seen >= 2 and len(self._graphs) < self.graphs:
                             ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None)
                     if ent is not None:
+                        cur = torch.cuda.current_stream(input_ids.device)
+                        if ent.get("stream") is not None and ent["stream"] != cur:
+                            cur.wait_stream(ent["stream"])          # a caller on another stream: order behind the last reader of the buffers
+                        ent["stream"] = cur
                         ent["ids"].copy_(input_ids, non_blocking=True)
                         ent["lens"].copy_(lens_host, non_blocking=True)
                         if token_type_ids is not None:
