@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--index-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="route selector passed to cmr_index_set_option on this rank's index (A/B runs; DESIGN.md appendix)")
+    ap.add_argument("--only-config3", action="store_true", help="after the headline, run the batch-256 row and skip the other extras")
     return ap.parse_args()
 
 
@@ -90,6 +93,9 @@ def build_shard(torch, args, rows, rank, world, device, host=None, timing=False)
             host[at:at + len(blk)] = blk.cpu().numpy()
         at += len(blk)
     torch.cuda.synchronize(device)
+    for opt in args.index_option:
+        name, _, value = opt.partition("=")
+        sh.local.set_option(name.strip(), int(value))
     return sh
 
 
@@ -362,7 +368,7 @@ def main():
 
     # fp32 host copy of the corpus for the CPU legs (rank 0, N=1 only): needs rows*dim*4 bytes + slack
     host = None
-    want_cpu = rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline
+    want_cpu = rank == 0 and world == 1 and not args.no_extra and not args.no_cpu_baseline and not args.only_config3
     if want_cpu:
         try:
             import psutil
@@ -451,7 +457,7 @@ def main():
     extra = {}
     if c3 is not None:
         extra["config3_batch256"] = c3
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and world == 1 and not args.no_extra and not args.only_config3:
         q = qs
         from comorag_amd.sharded import ShardedIndex
         # BASELINE config 2 (1 M rows) and one 8-GPU shard of config 3 (1.25 M rows) on this GPU

@@ -119,7 +119,9 @@ struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullp
 // sp / sm / sm2: pre-phase and main scans of batches of <= 64 queries (with CU masks: sm, sm2 on n_cu - 64 CUs, sp on the other
 // 64); wp / wm: the same for wide batches (no masks: the wide kernel is matrix-pipe-bound and wants every CU); sq: candidate
 // merges and whatever the caller appends behind a batch (no mask: its small workgroups fit beside a scan workgroup on any CU)
-struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sm2 = nullptr, wp = nullptr, wm = nullptr, wm2 = nullptr, sq = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; unsigned nscan = 0, nwscan = 0; int scan_cus = 0, wide_cus = 0; };
+// usp / usm / uwp / uwm: unmasked twins of sp / sm / wp / wm, created with them — scans of a millisecond and longer run there
+// (pipe_cu_mask = -1): the masks pay where ramp, tail and packet gaps are a visible share of a step, and cost a long scan CUs.
+struct Pipe { hipStream_t sp = nullptr, sm = nullptr, sm2 = nullptr, wp = nullptr, wm = nullptr, wm2 = nullptr, sq = nullptr, usp = nullptr, usm = nullptr, uwp = nullptr, uwm = nullptr; PipeSlot slot[CMR_PIPE_SLOTS]; unsigned next = 0; int nslots = 2; unsigned nscan = 0, nwscan = 0; int scan_cus = 0, wide_cus = 0; int last_masked = 0; };
 
 }  // namespace
 
@@ -164,7 +166,7 @@ struct cmr_index {
     int dual_scan = -1;      // pipe_dual_scan: -1 (default: with the masks, for scans shorter than 1 ms) | 1 (always) | 0 (never): main scans alternate between two streams, so the next scan's workgroups take over the CUs this
                              // scan's workgroups leave (no idle gap between two scans); needs pipe_cu_mask, else the next scan would simply
                              // occupy the CUs left free for the pre-phase
-    int cu_mask = -1;        // pipe_cu_mask = 1 (default on a 256-CU device) | 2 | 0 (off): the scan stream(s) are created with a CU mask of n_cu - 64 CUs, the pre-phase / merge streams
+    int cu_mask = -1;        // pipe_cu_mask = -1 (default on a 256-CU device: scans shorter than 1 ms) | 1 | 2 (every scan) | 0 (off): scan stream(s) with a CU mask of n_cu - 64 CUs, the pre-phase streams
                              // with the other 64 (1: mask bits interleave the XCDs — the amdgpu driver's enumeration; 2: 32 consecutive bits per XCD)
     int wide_abl = 0;        // development builds only
     int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
@@ -666,6 +668,7 @@ int ensure_pipe(cmr_index* idx) {
         if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&P.sm2, 8, scan));
         HIP_TRY(hipExtStreamCreateWithCUMask(&P.sp, 8, rest));
         P.scan_cus = idx->n_cu - 64;
+        for (hipStream_t* st : {&P.usp, &P.usm, &P.uwp, &P.uwm}) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     } else {
         HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
@@ -693,9 +696,18 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
     const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
+    // Scans shorter than 1 ms at the streaming rate (shards up to ~4 M x 768 bf16 rows) run on the CU-masked streams — and
+    // alternate between two of them; longer ones on the unmasked twins with the trimmed grid: in bench.py's flow the masks cost
+    // the 10 M-row scans CUs (same-box A/B: B = 64 step 2.441 vs 2.396 ms, B = 256 4.444 vs 4.069) where they bought the
+    // short ones 7-8 %.  pipe_cu_mask = 1 | 2 forces the masks for every scan, 0 creates none.
+    const double scan_us = (double)((idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS) * idx->panel_bytes() / 6.0e6;
+    const bool masked = P.scan_cus != 0 && (idx->cu_mask > 0 || scan_us < 1000.0);
+    const bool twins = P.scan_cus != 0 && !masked;      // masked streams exist but this call's scans use the unmasked ones
+    P.last_masked = masked ? 1 : 0;
+    hipStream_t const nsp = twins ? P.usp : P.sp, wsp = twins ? P.uwp : P.wp;
     if (wait_event) {      // inputs ready: both pre-phase streams may read them
-        HIP_TRY(hipStreamWaitEvent(P.sp, wait_event, 0));
-        if (wideq > 0 && nq > narrow) HIP_TRY(hipStreamWaitEvent(P.wp, wait_event, 0));
+        HIP_TRY(hipStreamWaitEvent(nsp, wait_event, 0));
+        if (wideq > 0 && nq > narrow) HIP_TRY(hipStreamWaitEvent(wsp, wait_event, 0));
     }
     PipeSlot* last = nullptr;
     for (int q0 = 0; q0 < nq;) {
@@ -703,7 +715,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         const bool wide = wideq > 0 && left > narrow;
         const int nqp = std::min(wide ? wideq : narrow, left);
         PipeSlot* sl = &P.slot[P.next++ % (unsigned)P.nslots];
-        hipStream_t sp = wide ? P.wp : P.sp;
+        hipStream_t sp = wide ? wsp : nsp;
         if (sl->used) {
             // The pre-phase rewrites the slot's query fragments / thresholds: free once the slot's previous
             // main scan is over.  Its candidate lists are still being merged (on sq) at that point, so only the
@@ -719,13 +731,13 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         // packet gap is 7-8 % of a step (1 M rows 0.270 -> 0.250 ms), at 10 M rows 2.7 % — and overlapping launches have no
         // per-launch duration any more (a kernel's begin-to-end then includes the wait for the previous scan's CUs), which
         // is what the roofline of the long headline scan is measured with.
-        const double scan_us = (double)((idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS) * idx->panel_bytes() / 6.0e6;
-        const bool dual = (wide ? P.wm2 != nullptr : P.sm2 != nullptr) && (idx->dual_scan > 0 || scan_us < 1000.0);
+        const bool dual = !twins && (wide ? P.wm2 != nullptr : P.sm2 != nullptr) && (idx->dual_scan > 0 || scan_us < 1000.0);
         if (!wide) idx->dual_active = dual ? 1 : 0;
         else idx->dual_wide_active = dual ? 1 : 0;
-        hipStream_t sm = wide ? ((dual && (P.nwscan++ & 1)) ? P.wm2 : P.wm) : ((dual && (P.nscan++ & 1)) ? P.sm2 : P.sm);
+        hipStream_t sm = twins ? (wide ? P.uwm : P.usm)
+                               : wide ? ((dual && (P.nwscan++ & 1)) ? P.wm2 : P.wm) : ((dual && (P.nscan++ & 1)) ? P.sm2 : P.sm);
         int rc = enqueue_pass(idx, &sl->ws, sp, sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
-                              (!wide && P.scan_cus) ? idx->n_cu - P.scan_cus : (wide && P.wide_cus) ? idx->n_cu - P.wide_cus : idx->reserve_cus,
+                              (masked && !wide) ? idx->n_cu - P.scan_cus : (masked && wide) ? idx->n_cu - P.wide_cus : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
                               max_dev ? max_dev + q0 : nullptr, wide);
         if (rc) return rc;
@@ -937,6 +949,7 @@ int32_t cmr_index_destroy(cmr_index_t* idx) {
         if (idx->pipe.wp) (void)hipStreamDestroy(idx->pipe.wp);
         if (idx->pipe.wm) (void)hipStreamDestroy(idx->pipe.wm);
         if (idx->pipe.wm2) (void)hipStreamDestroy(idx->pipe.wm2);
+        for (hipStream_t st : {idx->pipe.usp, idx->pipe.usm, idx->pipe.uwp, idx->pipe.uwm}) if (st) (void)hipStreamDestroy(st);
         if (idx->pipe.sq) (void)hipStreamDestroy(idx->pipe.sq);
         idx->stage.release();
         if (idx->h_pin) { (void)hipHostFree(idx->h_pin); idx->h_pin = nullptr; idx->h_pin_cap = 0; }
@@ -1137,8 +1150,8 @@ int32_t cmr_index_get_option(cmr_index_t* idx, const char* name, int64_t* value)
     const std::string n(name);
     if (n == "pipe_dual_scan_active") *value = idx->dual_active;
     else if (n == "pipe_dual_scan_wide_active") *value = idx->dual_wide_active;
-    else if (n == "pipe_cu_mask_active") *value = idx->pipe.scan_cus ? 1 : 0;
-    else if (n == "pipe_scan_cus") *value = idx->pipe.scan_cus ? idx->pipe.scan_cus : idx->n_cu;
+    else if (n == "pipe_cu_mask_active") *value = idx->pipe.last_masked;
+    else if (n == "pipe_scan_cus") *value = idx->pipe.last_masked ? idx->pipe.scan_cus : idx->n_cu;
     else return fail(CMR_ERR_INVALID, "unknown readable option '%s'", name);
     return CMR_OK;
 }
@@ -1152,7 +1165,8 @@ int32_t cmr_index_pipeline_stream(cmr_index_t* idx, int32_t which, void** stream
     Pipe& P = idx->pipe;
     rc = ensure_pipe(idx);
     if (rc) return rc;
-    *stream = which == 0 ? (void*)P.sp : which == 1 ? (void*)P.sm : (void*)P.sq;
+    const bool twins = P.scan_cus != 0 && !P.last_masked && P.next != 0;      // the set the last narrow batch ran on
+    *stream = which == 0 ? (void*)(twins ? P.usp : P.sp) : which == 1 ? (void*)(twins ? P.usm : P.sm) : (void*)P.sq;
     return CMR_OK;
 }
 
@@ -1167,7 +1181,7 @@ int32_t cmr_index_query_status(cmr_index_t* idx, int32_t* nonfinite) {
         std::lock_guard<std::mutex> pl(idx->pipe_mu);
         for (int i = 0; i < CMR_PIPE_SLOTS; ++i) if (idx->pipe.slot[i].used) wss.push_back(&idx->pipe.slot[i].ws);
         if (idx->pipe.sq) {
-            for (hipStream_t st : {idx->pipe.sp, idx->pipe.sm, idx->pipe.sm2, idx->pipe.wp, idx->pipe.wm, idx->pipe.wm2, idx->pipe.sq})
+            for (hipStream_t st : {idx->pipe.sp, idx->pipe.sm, idx->pipe.sm2, idx->pipe.wp, idx->pipe.wm, idx->pipe.wm2, idx->pipe.usp, idx->pipe.usm, idx->pipe.uwp, idx->pipe.uwm, idx->pipe.sq})
                 if (st) HIP_TRY(hipStreamSynchronize(st));
         }
     }

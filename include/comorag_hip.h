@@ -122,9 +122,10 @@ int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t n
 
 /* Throughput mode for a stream of independent query batches (serving; bench.py).  Work is enqueued on streams owned by
  * the index: query packing + sampling passes of batch i+1 overlap the HBM-bound main scan of batch i.  On a 256-CU device
- * the main scans of batches of <= 64 queries run on a CU-masked pair of streams (n_cu - 64 CUs; consecutive scans shorter than
- * ~1 ms alternate between the two, so one scan's workgroups take over the CUs the previous scan's workgroups leave) and their
- * pre-phases on the other 64 CUs; wide batches likewise on n_cu - 32 / 32 CUs.  wait_event (hipEvent_t or NULL): inputs are ready when it
+ * main scans shorter than ~1 ms (shards up to ~4 M x 768 bf16 rows) of batches of <= 64 queries run on a CU-masked pair of
+ * streams (n_cu - 64 CUs; consecutive scans alternate between the two, so one scan's workgroups take over the CUs the previous
+ * scan's workgroups leave) and their pre-phases on the other 64 CUs, wide batches likewise on n_cu - 32 / 32 CUs; longer scans
+ * run on unmasked streams with a trimmed grid.  wait_event (hipEvent_t or NULL): inputs are ready when it
  * completes.  *done_event (hipEvent_t owned by the index): outputs are complete when it does; it is re-recorded three
  * pipelined calls later (the pipeline has three slots), so wait on it (hipStreamWaitEvent / hipEventSynchronize) before
  * then.  k <= CMR_MAX_K.  Results are identical to cmr_index_search_dev.                                               */
@@ -148,7 +149,7 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * shipped library.  Names: scan_ring (8 | 16), scan_asm_ring (0 | 1), scan_grid, scan_no_sample, scan_no_wide (batches of
  * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
  * paths), zero_copy, sample_single, sample_tau_in_scan, sample_div, sample_maxmul, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
- * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0 | 1 | 2) and
+ * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0: never | 1 | 2: every scan; default: scans shorter than ~1 ms) and
  * pipe_dual_scan (0 | 1; default: scans shorter than ~1 ms) — the pipelined search's streams with explicit CU masks (scans
  * of <= 64-query batches on n_cu - 64 CUs, their pre-phases on the other 64) and two alternating scan streams; both must
  * be set before the first pipelined call.
