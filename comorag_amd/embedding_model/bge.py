@@ -200,12 +200,19 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             if self._fused is not None and not inputs["attention_mask"].is_cuda:
                 from .fused_bert import lens_of_mask
                 lens = lens_of_mask(inputs["attention_mask"].numpy())      # None unless every row is ones-then-zeros
-            inputs = {k: (v.pin_memory() if not v.is_cuda else v).to(self.device, non_blocking=True) for k, v in inputs.items()}
+            inputs = {k: (v if v.is_cuda else self._upload(v)) for k, v in inputs.items()}
             if lens is not None:
-                return self._fused(inputs["input_ids"], lens, token_type_ids=inputs.get("token_type_ids"),
+                return self._fused(inputs["input_ids"], self._upload(torch.from_numpy(lens)), token_type_ids=inputs.get("token_type_ids"),
                                    consume=lambda hidden: pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize))
             hidden = self.embedding_model(**inputs).last_hidden_state
             return pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize)
+
+    def _upload(self, host):
+        """Host tensor → device, asynchronously, on the caller's stream (pinned: a copy from pageable memory makes the host wait
+        for everything queued on the stream).  Measured and dropped (profiles/r3_measurements.md): a staging ring of this
+        model's own — every block stays busy until the GPU has worked off the forwards queued before its copy, so the host
+        ends up waiting on the oldest; the same ring on a copy stream of its own moves that wait into the device allocator."""
+        return host.pin_memory().to(self.device, non_blocking=True)
 
     def _encode(self, prompts: Union[str, List[str]], **kwargs):
         """BGEEmbedding.py:92-129 for one mini-batch; returns a torch fp32 tensor [b, D] on the GPU."""
@@ -277,7 +284,11 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     collect = lambda jobs: [x for j in jobs for x in j.result()]
                 look = 3                                   # windows being tokenised ahead of the one on the GPU
                 pending = [submit(w) for w in windows[:look]]
-                results, base, budget = None, 0, batch_size * ml
+                # token budget of a mini-batch: `embedding_forward_batches` reference batches' worth.  The GEMMs of a 128 x 512-token
+                # forward run 16 % faster per chunk than those of a 32 x 512 one (forward alone 7.4 -> 8.6 K chunks/s), but end to
+                # end the larger staging copies cost the host more than that (6.5-7.1 K -> 2.7-3.4 K chunks/s): default 1
+                fwb = max(1, int(cfg_get(self.global_config, "embedding_forward_batches", 1)))
+                results, base, budget = None, 0, fwb * batch_size * ml
                 trace = getattr(self, "_trace", None)       # a list: per window (seconds waiting for token ids, seconds launching)
                 import time as _time
                 for wi in range(len(windows)):
@@ -302,7 +313,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     if results is None:
                         results = torch.empty((len(texts), parts[0].shape[1]), dtype=parts[0].dtype, device=parts[0].device)
                     # (pinned index: a pageable copy would hold the host until this window's forwards have all finished)
-                    where = torch.from_numpy(np.concatenate(groups) + base).pin_memory().to(results.device, non_blocking=True)
+                    where = self._upload(torch.from_numpy(np.concatenate(groups) + base))
                     results[where] = torch.cat(parts, dim=0)
                     base += len(id_lists)
                     if trace is not None:

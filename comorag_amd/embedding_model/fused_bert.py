@@ -147,7 +147,8 @@ class FusedBertLayers:
         return x.view(b, l, self.hidden)
 
     def __call__(self, input_ids, lens: np.ndarray, token_type_ids=None, consume=None):
-        """input_ids [b, l] int64 on the GPU (right-padded), lens[b] real token counts (host) → last hidden state [b, l, hidden];
+        """input_ids [b, l] int64 on the GPU (right-padded), lens[b] real token counts (host array, or an int32 tensor already
+        on the GPU) → last hidden state [b, l, hidden];
         with `consume`, returns consume(hidden) instead.
 
         A mini-batch shape seen before runs as ONE captured hipGraph (`graphs` > 0: up to that many shapes are kept, captured at
@@ -159,7 +160,10 @@ class FusedBertLayers:
         b, l = input_ids.shape
         with torch.no_grad():
             # (pinned: a copy from pageable memory makes the host wait for everything queued on the stream before it)
-            lens_host = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).pin_memory()
+            if isinstance(lens, torch.Tensor) and lens.is_cuda:
+                lens_src = lens.to(torch.int32)              # already uploaded by the caller (its own pinned staging ring)
+            else:
+                lens_src = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).pin_memory()
             key = (b, l, token_type_ids is not None)
             if self.graphs > 0:
                 with self._glock:
@@ -174,12 +178,12 @@ class FusedBertLayers:
                             cur.wait_stream(ent["stream"])          # a caller on another stream: order behind the last reader of the buffers
                         ent["stream"] = cur
                         ent["ids"].copy_(input_ids, non_blocking=True)
-                        ent["lens"].copy_(lens_host, non_blocking=True)
+                        ent["lens"].copy_(lens_src, non_blocking=True)
                         if token_type_ids is not None:
                             ent["tt"].copy_(token_type_ids, non_blocking=True)
                         ent["graph"].replay()
                         return consume(ent["hidden"]) if consume is not None else ent["hidden"].clone()
-            hidden = self._stack(input_ids, lens_host.to(input_ids.device, non_blocking=True), token_type_ids)
+            hidden = self._stack(input_ids, lens_src.to(input_ids.device, non_blocking=True), token_type_ids)
             return consume(hidden) if consume is not None else hidden
 
     def _capture(self, b: int, l: int, has_tt: bool):

@@ -33,6 +33,7 @@ class BaseConfig:
     embedding_tokenizer_threads: int = 2          # host threads tokenising ahead of the forward
     embedding_bucket_window: int = 4              # length bucketing sorts within windows of this many batches (the next windows are tokenised meanwhile)
     embedding_tokenizer_processes: int = 0        # > 0: tokenise in that many worker PROCESSES instead (the Rust tokenizer holds the GIL)
+    embedding_forward_batches: int = 1            # length-bucketed path: a forward mini-batch holds up to this many reference batches' worth of tokens
     embedding_hip_graphs: int = 24                # fused encoder: mini-batch shapes kept as captured hipGraphs (0 = launch every forward eagerly)
     embedding_fused_encoder: bool = True          # 16-bit BERT encoders: HIP attention + bias/residual/LayerNorm stages, one QKV GEMM (embedding_model/fused_bert.py)
 
