@@ -344,6 +344,8 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         return self.batch_encode(texts, _return_device=True, **kwargs)
 
     def close(self) -> None:
+        if getattr(self, "_fused", None) is not None:
+            self._fused.release()
         if getattr(self, "_tok_procs", None) is not None:
             self._tok_procs.terminate()
             self._tok_procs = None

@@ -169,6 +169,8 @@ class FusedBertLayers:
                 with self._glock:
                     ent = self._graphs.get(key)
                     if ent is None:
+                        if len(self._seen) > 4096:               # a corpus of ragged shapes: forget the counts, keep the graphs
+                            self._seen.clear()
                         seen = self._seen[key] = self._seen.get(key, 0) + 1
                         if seen >= 2 and len(self._graphs) < self.graphs:
                             ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None)
@@ -203,3 +205,9 @@ class FusedBertLayers:
             ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"])
         ent["graph"] = graph
         return ent
+
+    def release(self) -> None:
+        """Drop the captured graphs (their private memory pools go back to PyTorch's allocator)."""
+        with self._glock:
+            self._graphs.clear()
+            self._seen.clear()
