@@ -278,3 +278,21 @@ def test_private_backend_copies_equal_the_tokenizer_call_under_concurrency():
     with ThreadPoolExecutor(6) as ex:
         assert all(ex.map(one, [512, 64, 7] * 8))
     assert sorted(em._bt_copies) == [7, 64, 512]
+
+
+def test_fused_encoder_gate_and_mask_lengths():
+    """Host logic of the 16-bit layer stack (embedding_model/fused_bert.py): which models it accepts, and that only
+    ones-then-zeros attention masks are turned into per-sequence lengths (anything else keeps the transformers forward)."""
+    import torch
+    from comorag_amd.embedding_model import fused_bert
+    from oracle import encode_torch as enc
+    m32, _ = enc.tiny_bert(hidden=128, layers=1, heads=4, inter=256, max_pos=32)      # 32-wide heads
+    m64, _ = enc.tiny_bert(hidden=256, layers=1, heads=4, inter=512, max_pos=32)
+    assert "16-bit" in fused_bert.why_not(m64) and "head width" in fused_bert.why_not(m32.to(torch.bfloat16))
+    assert fused_bert.why_not(m64.to(torch.bfloat16)) is None and fused_bert.why_not(m64.to(torch.float16)) is None
+    m64.config.hidden_act = "relu"
+    assert "activation" in fused_bert.why_not(m64)
+    assert fused_bert.why_not(object()) == "not a BERT encoder"
+    assert fused_bert.lens_of_mask(np.array([[1, 1, 0, 0], [1, 1, 1, 1]])).tolist() == [2, 4]
+    for bad in ([[0, 1, 1]], [[1, 0, 1]], [[0, 0, 0]], [[1, 2, 0]], [1, 1, 0]):
+        assert fused_bert.lens_of_mask(np.array(bad)) is None
