@@ -39,7 +39,7 @@ SCAN_FLAGS = ["-mllvm", "-pragma-unroll-threshold=1048576"]
 SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip", "encoder_kernels.hip"]
 HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 
-_KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
+_KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
 
 
 def _regs(text: str) -> set:
@@ -66,7 +66,7 @@ def audit_ring(asm_text: str) -> dict:
         if not m:
             i += 1
             continue
-        dt, nqt, cap, ring, mode, asmring = (int(x) for x in m.groups())
+        dt, nqt, cap, ring, mode, asmring, _pol = (int(x) for x in m.groups())      # both cache-policy variants of a shape must pass
         j = i + 1
         body = []
         while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
@@ -111,7 +111,7 @@ def audit_ring(asm_text: str) -> dict:
                         ok = False
                 else:
                     ok = False
-        result[(dt, nqt, cap, ring, mode)] = ok
+        result[(dt, nqt, cap, ring, mode)] = ok and result.get((dt, nqt, cap, ring, mode), True)
     return result
 
 

@@ -17,6 +17,7 @@
 
 #include "../../include/comorag_hip.h"
 #include "cmr_kernels.h"
+#include "cmr_internal.h"
 
 #define CMR_DT_F32 0
 #define CMR_PANEL_ROWS 32
@@ -30,7 +31,7 @@ namespace {
 thread_local std::string g_err;
 }
 
-// sets the thread's error message; also used by comm.hip
+// sets the thread's error message; also used by comm.hip / multi.hip
 int cmr_fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -169,6 +170,9 @@ struct cmr_index {
     int cu_mask = -1;        // pipe_cu_mask = -1 (default on a 256-CU device: scans shorter than 1 ms) | 1 | 2 (every scan) | 0 (off): scan stream(s) with a CU mask of n_cu - 64 CUs, the pre-phase streams
                              // with the other 64 (1: mask bits interleave the XCDs — the amdgpu driver's enumeration; 2: 32 consecutive bits per XCD)
     int wide_abl = 0;        // development builds only
+    int stream_nt = -1;      // stream_nt: -1 default (non-temporal corpus loads, default policy for the query-split grid) | 0 | 1: force
+    int wide_mode = 0;       // wide_mode: batches of more than one narrow pass — 1: the register-resident wide kernel, 2: the query-split grid of the
+                             // narrow kernel (up to 4 query tiles walk the same panel ranges on CUs of one XCD; any dim / dtype), 0: the measured default
     int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
     int dual_wide_active = 0;   // read-only ("pipe_dual_scan_wide_active"): the same for the last wide pass
     int dual_active = 0;     // read-only ("pipe_dual_scan_active"): did the last pipelined <= 64-query pass alternate between the two scan streams
@@ -212,6 +216,8 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "pipe_reserve_cus") idx->reserve_cus = (int)v;
     else if (n == "pipe_slots") idx->pipe_slots = (int)v;
     else if (n == "wide_waves") { if (v != 0 && v != 4 && v != 8) return fail(CMR_ERR_INVALID, "wide_waves must be 0 (default), 4 or 8"); idx->wide_waves = (int)v; }
+    else if (n == "wide_mode") { if (v < 0 || v > 2) return fail(CMR_ERR_INVALID, "wide_mode must be 0 (default), 1 (register-resident kernel) or 2 (query-split grid)"); idx->wide_mode = (int)v; }
+    else if (n == "stream_nt") idx->stream_nt = (int)v;
     else if (n == "pipe_dual_scan") idx->dual_scan = (int)v;
     else if (n == "pipe_cu_mask") idx->cu_mask = (int)v;
 #ifdef CMR_DEV_KNOBS
@@ -226,7 +232,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
                                   "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_tau_in_scan", "sample_div", "sample_maxmul", "pipe_reserve_cus",
-                                  "pipe_slots", "wide_waves", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
+                                  "pipe_slots", "wide_waves", "wide_mode", "stream_nt", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
         for (const char* c = nm; *c; ++c) env += (char)toupper(*c);
@@ -410,15 +416,22 @@ int balanced_grid(long long npanels, int grid, int lists_per_wg) {
 int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, hipStream_t sq, hipEvent_t ev_pre, hipEvent_t ev_scan,
                  hipEvent_t ev_lists_free, const float* q_dev, int nqp,
                  int k, int reserve_cus, int64_t* ids_dev, float* scores_dev, float* min_dev, float* max_dev, bool wide = false,
-                 const float* min_score = nullptr) {
+                 const float* min_score = nullptr, bool quad = false) {
+    // quad: a batch of more than one narrow pass on the query-split grid of the NARROW kernel (scan_kernel, qgroups): the
+    // caller picks the streams as for a wide pass; geometry, lists and sampling are the narrow kernel's, one set per group
     CmrScanGeom g{};
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
     int rc = arm_flag(ws, sp);   // zeroed once; the reader re-arms it after reporting
     if (rc) return rc;
-    rc = make_geom(idx, nqp, k, true, &g);
+    if (quad) wide = false;
+    const int narrow_cap = cmr_scan_max_nqt(idx->dtype, idx->dpad) >= 2 ? 64 : 32;
+    rc = make_geom(idx, quad ? std::min(nqp, narrow_cap) : nqp, k, true, &g);
     if (rc) return rc;
     g.wide_waves = idx->wide_waves;
     g.wide_abl = idx->wide_abl;
+    const int G = quad ? (nqp + g.nqt * 32 - 1) / (g.nqt * 32) : 1;      // query groups
+    // the groups' twins re-read each corpus block from L2: default cache policy for them, non-temporal for single-group scans
+    g.stream_default_policy = idx->stream_nt < 0 ? (G > 1 ? 1 : 0) : (idx->stream_nt ? 0 : 1);
     const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
     // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
     // best of that sample per query as the threshold of the next level / of the main scan.  Any
@@ -473,7 +486,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
             // nothing measurable at 10 M).  Measured at 1 / 1.25 / 2.5 / 5 / 10 M rows x 768 bf16.
             const double scan_us = (double)npanels * idx->panel_bytes() / 6.0e6;
             const long long rounds = (long long)((0.7 * scan_us - 200.0) / 200.0);
-            const long long wgs = std::max<long long>(1, (max_sample + lists_per_wg - 1) / lists_per_wg);
+            const long long wgs = std::max<long long>(1, (max_sample + lists_per_wg - 1) / lists_per_wg) * G;
             reserve_cus = rounds >= 1 ? (int)std::min<long long>(64, std::max<long long>(8, (wgs + rounds - 1) / rounds)) : 64;
         }
     }
@@ -496,30 +509,40 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         g.grid = (int)std::max<long long>(1, std::min<long long>(npanels, idx->n_cu));
         if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
         NQ = nqb; W = g.grid; tiles = nqb / 32;
+    } else if (G > 1) {
+        // query-split grid: G workgroups (one per query tile) share every virtual workgroup's panel ranges; the virtual grid is
+        // a multiple of 8 so that the G twins land on one XCD (scan_kernel) and G x virtual grid fills the CUs once
+        if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
+        int vg = g.grid / G;
+        if (vg >= 8) vg &= ~7;
+        g.grid = std::max(vg, 1);
+        NQ = g.nqt * 32; W = g.grid * CMR_SCAN_WAVES; tiles = G * g.nqt;
     } else {
         if (reserve_cus > 0 && g.grid > idx->n_cu / 2) g.grid = std::max(g.grid - reserve_cus, idx->n_cu / 2);
         if (!idx->force_grid) g.grid = balanced_grid(npanels, g.grid, CMR_SCAN_WAVES);
         NQ = g.nqt * 32; W = g.grid * CMR_SCAN_WAVES; tiles = g.nqt;
     }
+    const int NQA = G * NQ;          // query slots of the pass over all groups
     // sample passes and the main pass use separate list buffers: in pipelined mode the next batch's
     // sampling runs while this batch's main scan still owns `lists`
     HIP_TRY(ws->qfrag.ensure((size_t)tiles * g.ks * 1024));
-    HIP_TRY(ws->lists.ensure((size_t)W * NQ * g.cap * 8));
-    HIP_TRY(ws->cnt.ensure((size_t)W * NQ * 4));
-    HIP_TRY(ws->mm.ensure((size_t)W * NQ * 8));
+    HIP_TRY(ws->lists.ensure((size_t)W * NQA * g.cap * 8));
+    HIP_TRY(ws->cnt.ensure((size_t)W * NQA * 4));
+    HIP_TRY(ws->mm.ensure((size_t)W * NQA * 8));
     if (Ws) {
-        HIP_TRY(ws->s_lists.ensure((size_t)Ws * NQ * g.cap * 8));
-        HIP_TRY(ws->s_cnt.ensure((size_t)Ws * NQ * 4));
-        HIP_TRY(ws->s_mm.ensure((size_t)Ws * NQ * 8));
+        HIP_TRY(ws->s_lists.ensure((size_t)Ws * NQA * g.cap * 8));
+        HIP_TRY(ws->s_cnt.ensure((size_t)Ws * NQA * 4));
+        HIP_TRY(ws->s_mm.ensure((size_t)Ws * NQA * 8));
     }
-    HIP_TRY(ws->tau.ensure((size_t)2 * NQ * 8));
+    HIP_TRY(ws->tau.ensure((size_t)2 * NQA * 8));
     HIP_TRY(cmr_launch_prep_queries(idx->dtype, q_dev, nqp, idx->dim, idx->dpad, tiles, ws->qfrag.p, ws->flag_ptr, sp));
     CmrScanArgs a{};
     a.corpus = idx->corpus; a.qfrag = ws->qfrag.p; a.nrows = idx->n; a.npanels = (int)npanels; a.k = k;
     a.nq = nqp;
+    a.qgroups = G;
     if (min_score) {
         // key > tau  <=>  score >= *min_score: tau = (smallest key with that score) - 1
-        HIP_TRY(cmr_launch_fill_threshold(*min_score, NQ, (u64*)ws->tau.p, sp));
+        HIP_TRY(cmr_launch_fill_threshold(*min_score, NQA, (u64*)ws->tau.p, sp));
         a.tau_init = (u64*)ws->tau.p;
     }
     for (int lv = 0; lv < n_levels; ++lv) {
@@ -527,6 +550,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         CmrScanGeom gs = g;
         gs.grid = sample_grid(spn);
         const int Wl = gs.grid * lists_per_wg;
+        gs.grid *= G;                               // (query-split grid: every group samples the same panels)
         CmrScanArgs as = a;
         as.lists = (u64*)ws->s_lists.p; as.cnt = (int*)ws->s_cnt.p; as.mm = (float2*)ws->s_mm.p;
         // chunks of 8 consecutive panels (384 KiB at 768-d bf16), chunk starts spread evenly over the corpus: a sampling
@@ -535,7 +559,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         const int clog = spn >= 64 ? 3 : 0;
         const long long nchunks = (spn + (1 << clog) - 1) >> clog;
         as.sample_waves = (int)spn; as.sample_chunk_log2 = clog; as.sample_stride = (int)(npanels / nchunks);
-        u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQ;
+        u64* tau_out = (u64*)ws->tau.p + (size_t)(lv & 1) * NQA;
         HIP_TRY(wide ? cmr_launch_scan_wide(gs, as, sp) : cmr_launch_scan_topk(gs, as, sp));
         if (single_level && idx->tau_in_scan && NQ == 32 && nqp <= 2 && k <= 64) {
             // the one sampling level of ONE or TWO queries (what a synchronous caller issues): the main scan's workgroups derive
@@ -547,7 +571,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
             continue;
         }
         HIP_TRY(cmr_launch_merge_query((const u64*)ws->s_lists.p, (const int*)ws->s_cnt.p, Wl, NQ, g.cap, nqp, k, nullptr, 0, nullptr,
-                                       nullptr, nullptr, nullptr, tau_out, sp));
+                                       nullptr, nullptr, nullptr, tau_out, sp, G > 1));
         a.tau_init = tau_out;
     }
     if (sp != sm) {
@@ -567,6 +591,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(hipEventCreate(&pe.b));
         HIP_TRY(hipEventRecord(pe.a, sm));
     }
+    if (G > 1) g.grid *= G;
     HIP_TRY(wide ? cmr_launch_scan_wide(g, a, sm) : cmr_launch_scan_topk(g, a, sm));
     if (prof) {
         HIP_TRY(hipEventRecord(pe.b, sm));
@@ -579,8 +604,26 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(hipStreamWaitEvent(sq, ev_scan, 0));
     }
     HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, (const float2*)ws->mm.p,
-                                   kernel_id_base(idx), ids_dev, scores_dev, min_dev, max_dev, nullptr, sq));
+                                   kernel_id_base(idx), ids_dev, scores_dev, min_dev, max_dev, nullptr, sq, G > 1));
     return remap_ids_enqueue(idx, ids_dev, (long long)nqp * k, sq);
+}
+
+// Batches of more than one narrow pass: which kernel runs them, and how many queries it takes per corpus pass (0 = narrow passes).
+// wide_mode 1: the register-resident wide kernel only (768-d: 256 queries, 1024-d: 128; 16-bit indexes) — other shapes run
+// narrow passes; 2: always the query-split grid of the narrow kernel (4 tiles of 64 — or of 32 where the LDS holds one tile —
+// in one pass, any dim and dtype); 0 (default): the wide kernel where it exists, the query-split grid everywhere else.
+// Measured (profiles/r4_measurements.md, MI355X, 768-d bf16): at 10 M rows the wide kernel runs B = 256 in 3.79 ms, the grid in
+// 6.24 (its twins stay in step only partly: 43 % L2 hits of an ideal 75 %, the rest comes over the fabric), four narrow passes in
+// 9.4; at B = 128 the grid is level with the wide kernel (3.47 vs 3.26 ms; 0.39 vs 0.47 on a 1.25 M-row shard).
+bool wide_pass_is_quad(const cmr_index* idx) {
+    if (idx->wide_mode == 2) return true;
+    if (idx->wide_mode == 1) return false;
+    return cmr_wide_queries(idx->dtype, idx->dpad) == 0;
+}
+int wide_pass_queries(const cmr_index* idx) {
+    if (idx->no_wide) return 0;
+    if (!wide_pass_is_quad(idx)) return cmr_wide_queries(idx->dtype, idx->dpad);
+    return 4 * (cmr_scan_max_nqt(idx->dtype, idx->dpad) >= 2 ? 64 : 32);
 }
 
 // 0: the general pack / [sample] / scan / merge chain; 1: single launch, <= 1024 rows; 2: single launch, hierarchical
@@ -615,27 +658,30 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         return remap_ids_enqueue(idx, ids_dev, (long long)nq * k, ws->stream);
     }
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
-    const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
+    const int wideq = wide_pass_queries(idx);
+    const bool quad = wide_pass_is_quad(idx);
     for (int q0 = 0; q0 < nq;) {
         const int left = nq - q0;
         const bool wide = wideq > 0 && left > narrow;          // more than one narrow pass left: go wide
         const int nqp = std::min(wide ? wideq : narrow, left);
         int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr, wide, min_score);
+                              max_dev ? max_dev + q0 : nullptr, wide && !quad, min_score, wide && quad);
         if (rc) return rc;
         q0 += nqp;
     }
     return CMR_OK;
 }
 
-// Streams and per-slot events of the pipelined search, created on first use (idx->pipe_mu held).
-int ensure_pipe(cmr_index* idx) {
-    Pipe& P = idx->pipe;
-    if (P.sq) return CMR_OK;
-    const int mask = idx->cu_mask < 0 ? (idx->n_cu == 256 ? 1 : 0) : (idx->n_cu == 256 ? idx->cu_mask : 0);
-    const bool dual = idx->dual_scan < 0 ? mask != 0 : idx->dual_scan != 0;
-    HIP_TRY(hipStreamCreateWithFlags(&P.sq, hipStreamNonBlocking));
+// Streams and per-slot events of the pipelined search, created on first use (idx->pipe_mu held).  Everything is built into
+// locals and committed to idx->pipe only when ALL of it exists: a failure half way leaves the index without a pipeline (the next
+// call tries again), never with a half-built one that a later call would take for complete.  A device / driver that refuses
+// CU-masked streams gets plain streams (the masks buy time, not results).
+void destroy_streams(std::initializer_list<hipStream_t*> sts) {
+    for (hipStream_t* st : sts) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+}
+int create_pipe_streams(cmr_index* idx, Pipe& T, int mask, bool dual) {
+    HIP_TRY(hipStreamCreateWithFlags(&T.sq, hipStreamNonBlocking));
     if (mask) {
         // wide batches: the matrix-pipe-bound kernel wants CUs — n_cu - 32 for its scans (28 per XCD), the 32 it used to leave
         // free by trimming its grid for the pre-phase; two scan streams for short scans as below
@@ -644,15 +690,10 @@ int ensure_pipe(cmr_index* idx) {
             wscan[w] = mask == 2 ? 0x0FFFFFFFu : (w < 7 ? 0xFFFFFFFFu : 0u);
             wrest[w] = ~wscan[w];
         }
-        HIP_TRY(hipExtStreamCreateWithCUMask(&P.wm, 8, wscan));
-        if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&P.wm2, 8, wscan));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&P.wp, 8, wrest));
-        P.wide_cus = idx->n_cu - 32;
-    } else {
-        HIP_TRY(hipStreamCreateWithFlags(&P.wp, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&P.wm, hipStreamNonBlocking));
-    }
-    if (mask) {
+        HIP_TRY(hipExtStreamCreateWithCUMask(&T.wm, 8, wscan));
+        if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&T.wm2, 8, wscan));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&T.wp, 8, wrest));
+        T.wide_cus = idx->n_cu - 32;
         // Scans of the narrow kernel on n_cu - 64 CUs, their pre-phases on the other 64: the reservation that trimming the
         // grid only approximates, made explicit — and the precondition for TWO scan streams: the next scan's workgroups then
         // start on whatever CU of the scan set falls free (no idle gap, the tail of one scan under the ramp of the next),
@@ -664,22 +705,52 @@ int ensure_pipe(cmr_index* idx) {
             scan[w] = mask == 2 ? 0x00FFFFFFu : (w < 6 ? 0xFFFFFFFFu : 0u);      // 2: 24 of every 32 bits (same split if 32 consecutive bits were one XCD)
             rest[w] = ~scan[w];
         }
-        HIP_TRY(hipExtStreamCreateWithCUMask(&P.sm, 8, scan));
-        if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&P.sm2, 8, scan));
-        HIP_TRY(hipExtStreamCreateWithCUMask(&P.sp, 8, rest));
-        P.scan_cus = idx->n_cu - 64;
-        for (hipStream_t* st : {&P.usp, &P.usm, &P.uwp, &P.uwm}) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&T.sm, 8, scan));
+        if (dual) HIP_TRY(hipExtStreamCreateWithCUMask(&T.sm2, 8, scan));
+        HIP_TRY(hipExtStreamCreateWithCUMask(&T.sp, 8, rest));
+        T.scan_cus = idx->n_cu - 64;
+        for (hipStream_t* st : {&T.usp, &T.usm, &T.uwp, &T.uwm}) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     } else {
-        HIP_TRY(hipStreamCreateWithFlags(&P.sp, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&P.sm, hipStreamNonBlocking));
-        if (dual) HIP_TRY(hipStreamCreateWithFlags(&P.sm2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&T.wp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&T.wm, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&T.sp, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&T.sm, hipStreamNonBlocking));
+        if (dual) HIP_TRY(hipStreamCreateWithFlags(&T.sm2, hipStreamNonBlocking));
     }
+    return CMR_OK;
+}
+int ensure_pipe(cmr_index* idx) {
+    Pipe& P = idx->pipe;
+    if (P.sq) return CMR_OK;
+    int mask = idx->cu_mask < 0 ? (idx->n_cu == 256 ? 1 : 0) : (idx->n_cu == 256 ? idx->cu_mask : 0);
+    hipEvent_t ev[CMR_PIPE_SLOTS][3] = {};
+    Pipe T;
+    auto undo = [&]() {
+        destroy_streams({&T.sp, &T.sm, &T.sm2, &T.wp, &T.wm, &T.wm2, &T.sq, &T.usp, &T.usm, &T.uwp, &T.uwm});
+        for (auto& slot : ev) for (hipEvent_t& e : slot) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        T.scan_cus = T.wide_cus = 0;
+    };
+    int rc = create_pipe_streams(idx, T, mask, idx->dual_scan < 0 ? mask != 0 : idx->dual_scan != 0);
+    if (rc && mask) {                     // no CU-masked streams here: plain ones
+        undo();
+        mask = 0;
+        rc = create_pipe_streams(idx, T, 0, idx->dual_scan > 0);
+    }
+    if (rc) { undo(); return rc; }
+    auto make_events = [&]() -> int {
+        for (auto& slot : ev) for (hipEvent_t& e : slot) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return CMR_OK;
+    };
+    rc = make_events();
+    if (rc) { undo(); return rc; }
+    // commit (slots keep their workspaces: none exists before the first pipelined call)
+    P.sp = T.sp; P.sm = T.sm; P.sm2 = T.sm2; P.wp = T.wp; P.wm = T.wm; P.wm2 = T.wm2; P.usp = T.usp; P.usm = T.usm; P.uwp = T.uwp; P.uwm = T.uwm;
+    P.scan_cus = T.scan_cus; P.wide_cus = T.wide_cus;
     for (int i = 0; i < CMR_PIPE_SLOTS; ++i) {
-        HIP_TRY(hipEventCreateWithFlags(&P.slot[i].pre_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&P.slot[i].main_done, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&P.slot[i].scan_done, hipEventDisableTiming));
+        P.slot[i].pre_done = ev[i][0]; P.slot[i].main_done = ev[i][1]; P.slot[i].scan_done = ev[i][2];
         P.slot[i].ws.stream = P.sm;
     }
+    P.sq = T.sq;                          // the "pipeline exists" marker: last
     return CMR_OK;
 }
 
@@ -695,7 +766,8 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
     if (k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "pipelined search supports k <= %d", CMR_MAX_K);
     const int max_nqt = cmr_scan_max_nqt(idx->dtype, idx->dpad);
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
-    const int wideq = idx->no_wide ? 0 : cmr_wide_queries(idx->dtype, idx->dpad);
+    const int wideq = wide_pass_queries(idx);
+    const bool quad = wide_pass_is_quad(idx);
     // Scans shorter than 1 ms at the streaming rate (shards up to ~4 M x 768 bf16 rows) run on the CU-masked streams — and
     // alternate between two of them; longer ones on the unmasked twins with the trimmed grid: in bench.py's flow the masks cost
     // the 10 M-row scans CUs (same-box A/B: B = 64 step 2.441 vs 2.396 ms, B = 256 4.444 vs 4.069) where they bought the
@@ -739,7 +811,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         int rc = enqueue_pass(idx, &sl->ws, sp, sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
                               (masked && !wide) ? idx->n_cu - P.scan_cus : (masked && wide) ? idx->n_cu - P.wide_cus : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr, wide);
+                              max_dev ? max_dev + q0 : nullptr, wide && !quad, nullptr, wide && quad);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(sl->main_done, P.sq));
         sl->used = true;
@@ -1214,54 +1286,73 @@ int32_t cmr_event_synchronize(void* event) {
     return CMR_OK;
 }
 
-static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
-                           float* out_min, float* out_max, const float* min_score) {
-    if (!idx || !q || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
+}  // extern "C"
+
+// ---- synchronous host-buffer search in two halves (cmr_internal.h): `begin` enqueues everything on the workspace's stream and
+// returns without waiting, `finish` waits, checks the non-finite flag and copies the results out.  cmr_index_search is begin +
+// finish; the multi-device index (multi.hip) begins on every shard before it finishes on any, so all devices scan at once.
+struct CmrPending {
+    cmr_index* idx = nullptr;
+    Workspace* ws = nullptr;
+    bool locked = false;          // holds idx->mu shared (released by finish / abandon ON THE SAME THREAD)
+    bool mapped = false;          // results land in the pinned buffer by themselves (zero-copy) / by the enqueued D2H copy
+    int nq = 0, k = 0;
+    size_t o_ids = 0, o_sc = 0, o_min = 0, o_max = 0;
+};
+
+static void pending_release(CmrPending* p) {
+    if (p->ws) release_ws(p->idx, p->ws);
+    if (p->locked) p->idx->mu.unlock_shared();
+    delete p;
+}
+
+int cmr_index_search_begin(cmr_index_t* idx, const float* q, int nq, int k, const float* min_score, bool take_lock, CmrPending** out) {
+    if (!idx || !q || !out) return fail(CMR_ERR_INVALID, "NULL argument");
+    *out = nullptr;
     if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
     if (k <= 0 || k > CMR_MAX_K_2PASS) return fail(CMR_ERR_UNSUPPORTED, "k = %d outside [1, %d]", k, CMR_MAX_K_2PASS);
-    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    CmrPending* P = new CmrPending();
+    P->idx = idx; P->nq = nq; P->k = k;
+    if (take_lock) { idx->mu.lock_shared(); P->locked = true; }
     int rc = set_device(idx->device);
-    if (rc) return rc;
+    if (rc) { pending_release(P); return rc; }
     Workspace* ws = acquire_ws(idx, nullptr, false);
-    if (!ws) return fail(CMR_ERR_HIP, "could not create a workspace stream");
-    struct Rel { cmr_index* i; Workspace* w; ~Rel() { release_ws(i, w); } } rel{idx, ws};
+    if (!ws) { pending_release(P); return fail(CMR_ERR_HIP, "could not create a workspace stream"); }
+    P->ws = ws;
     hipStream_t s = ws->stream;
     // packed result buffer [flag (8 B) | ids nq*k i64 | scores nq*k f32 | min nq | max nq]
     const size_t o_ids = 8, o_sc = o_ids + (size_t)nq * k * 8, o_min = o_sc + (size_t)nq * k * 4, o_max = o_min + (size_t)nq * 4,
                  out_bytes = o_max + (size_t)nq * 4, q_bytes = (size_t)nq * idx->dim * 4;
-    const char* hp = nullptr;
-    if (idx->zero_copy && k <= CMR_MAX_K && q_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax) {
-        // (the hierarchical single-launch path packs the queries in up to 64 workgroups: they read a device copy, not
-        // 64 times across the link)
-        const bool map_in = small_path_kind(idx, nq, k, min_score != nullptr) != 2;
-        // Small calls (what ComoRAG issues: one query, a few hundred rows) are all latency.  A copy each way costs two more
-        // submissions in front of / behind the kernels (36 us per call at 6 rows, of which the search itself is ~8); so
-        // there are none: queries, results and the non-finite flag live in ONE pinned, device-mapped host buffer
-        // (fine-grained: kernel stores are visible once the stream has been synchronised) that the kernels read and
-        // write over PCIe themselves — a few KiB either way.
-        const size_t o_q = (out_bytes + 255) & ~(size_t)255;
-        HIP_TRY(ws->ensure_pin(o_q + q_bytes));
-        char* h = (char*)ws->h_pin;
-        char* d = (char*)ws->h_pin_dev;
-        memcpy(h + o_q, q, q_bytes);
-        memset(h, 0, 8);
-        const float* q_in = (const float*)(d + o_q);
-        if (!map_in) {
-            HIP_TRY(ws->d_q.ensure(q_bytes));
-            HIP_TRY(hipMemcpyAsync(ws->d_q.p, h + o_q, q_bytes, hipMemcpyHostToDevice, s));
-            q_in = (const float*)ws->d_q.p;
+    P->o_ids = o_ids; P->o_sc = o_sc; P->o_min = o_min; P->o_max = o_max;
+    auto body = [&]() -> int {
+        if (idx->zero_copy && k <= CMR_MAX_K && q_bytes <= kZeroCopyMax && out_bytes <= kZeroCopyMax) {
+            // (the hierarchical single-launch path packs the queries in up to 64 workgroups: they read a device copy, not
+            // 64 times across the link)
+            const bool map_in = small_path_kind(idx, nq, k, min_score != nullptr) != 2;
+            // Small calls (what ComoRAG issues: one query, a few hundred rows) are all latency.  A copy each way costs two more
+            // submissions in front of / behind the kernels (36 us per call at 6 rows, of which the search itself is ~8); so
+            // there are none: queries, results and the non-finite flag live in ONE pinned, device-mapped host buffer
+            // (fine-grained: kernel stores are visible once the stream has been synchronised) that the kernels read and
+            // write over PCIe themselves — a few KiB either way.
+            const size_t o_q = (out_bytes + 255) & ~(size_t)255;
+            HIP_TRY(ws->ensure_pin(o_q + q_bytes));
+            char* h = (char*)ws->h_pin;
+            char* d = (char*)ws->h_pin_dev;
+            memcpy(h + o_q, q, q_bytes);
+            memset(h, 0, 8);
+            const float* q_in = (const float*)(d + o_q);
+            if (!map_in) {
+                HIP_TRY(ws->d_q.ensure(q_bytes));
+                HIP_TRY(hipMemcpyAsync(ws->d_q.p, h + o_q, q_bytes, hipMemcpyHostToDevice, s));
+                q_in = (const float*)ws->d_q.p;
+            }
+            int* const dev_flag = ws->flag_ptr;
+            ws->flag_ptr = (int*)d;
+            const int rc_ = search_enqueue(idx, ws, q_in, nq, k, (int64_t*)(d + o_ids), (float*)(d + o_sc), (float*)(d + o_min), (float*)(d + o_max), min_score);
+            ws->flag_ptr = dev_flag;
+            P->mapped = true;
+            return rc_;
         }
-        int* const dev_flag = ws->flag_ptr;
-        ws->flag_ptr = (int*)d;
-        rc = search_enqueue(idx, ws, q_in, nq, k, (int64_t*)(d + o_ids), (float*)(d + o_sc), (float*)(d + o_min), (float*)(d + o_max), min_score);
-        ws->flag_ptr = dev_flag;
-        if (rc) { (void)hipStreamSynchronize(s); return rc; }
-        HIP_TRY(hipStreamSynchronize(s));
-        hp = h;
-        int flagged = 0;
-        memcpy(&flagged, hp, sizeof(int));
-        if (flagged) return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
-    } else {
         // packed device buffer and its pinned host twin, one copy each way; the queries go through the pinned buffer too (a
         // pageable H2D is staged by the runtime anyway)
         HIP_TRY(ws->d_q.ensure(q_bytes));
@@ -1272,28 +1363,75 @@ static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t
         }
         int* const dev_flag = ws->flag_ptr;
         ws->flag_ptr = (int*)ws->d_pack.p;
-        HIP_TRY(ws->ensure_pin(std::max(out_bytes, q_bytes)));
+        hipError_t e = ws->ensure_pin(std::max(out_bytes, q_bytes));
+        if (e != hipSuccess) { ws->flag_ptr = dev_flag; HIP_TRY(e); }
         memcpy(ws->h_pin, q, q_bytes);
-        HIP_TRY(hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s));
+        e = hipMemcpyAsync(ws->d_q.p, ws->h_pin, q_bytes, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { ws->flag_ptr = dev_flag; HIP_TRY(e); }
         char* pk = (char*)ws->d_pack.p;
-        rc = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max), min_score);
+        const int rc_ = search_enqueue(idx, ws, (const float*)ws->d_q.p, nq, k, (int64_t*)(pk + o_ids), (float*)(pk + o_sc), (float*)(pk + o_min), (float*)(pk + o_max), min_score);
         ws->flag_ptr = dev_flag;
-        if (rc) { (void)hipStreamSynchronize(s); return rc; }
+        if (rc_) return rc_;
+        // (the pinned buffer still holds the queries the H2D copy reads: stream order puts the D2H copy behind it)
         HIP_TRY(hipMemcpyAsync(ws->h_pin, pk, out_bytes, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        hp = (const char*)ws->h_pin;
-        int flagged = 0;
-        memcpy(&flagged, hp, sizeof(int));
-        if (flagged) {
-            HIP_TRY(hipMemsetAsync(ws->d_pack.p, 0, sizeof(int), s));
-            return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
-        }
-    }
-    memcpy(out_ids, hp + o_ids, (size_t)nq * k * 8);
-    memcpy(out_scores, hp + o_sc, (size_t)nq * k * 4);
-    if (out_min) memcpy(out_min, hp + o_min, (size_t)nq * 4);
-    if (out_max) memcpy(out_max, hp + o_max, (size_t)nq * 4);
+        return CMR_OK;
+    };
+    rc = body();
+    if (rc) { (void)hipStreamSynchronize(s); pending_release(P); return rc; }
+    *out = P;
     return CMR_OK;
+}
+
+int cmr_index_search_finish(CmrPending* P, int64_t* out_ids, float* out_scores, float* out_min, float* out_max) {
+    if (!P) return fail(CMR_ERR_INVALID, "NULL pending search");
+    struct Rel { CmrPending* p; ~Rel() { pending_release(p); } } rel{P};
+    int rc = set_device(P->idx->device);
+    if (rc) return rc;
+    Workspace* ws = P->ws;
+    HIP_TRY(hipStreamSynchronize(ws->stream));
+    const char* hp = (const char*)ws->h_pin;
+    int flagged = 0;
+    memcpy(&flagged, hp, sizeof(int));
+    if (flagged) {
+        if (!P->mapped) HIP_TRY(hipMemsetAsync(ws->d_pack.p, 0, sizeof(int), ws->stream));
+        return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");
+    }
+    const size_t nk = (size_t)P->nq * P->k;
+    if (out_ids) memcpy(out_ids, hp + P->o_ids, nk * 8);
+    if (out_scores) memcpy(out_scores, hp + P->o_sc, nk * 4);
+    if (out_min) memcpy(out_min, hp + P->o_min, (size_t)P->nq * 4);
+    if (out_max) memcpy(out_max, hp + P->o_max, (size_t)P->nq * 4);
+    return CMR_OK;
+}
+
+void cmr_index_search_abandon(CmrPending* P) {
+    if (!P) return;
+    (void)hipSetDevice(P->idx->device);
+    (void)hipStreamSynchronize(P->ws->stream);
+    // a query flagged non-finite leaves its mark in the packed DEVICE buffer of the copy path: clear it for the next call
+    if (!P->mapped && P->ws->d_pack.p) (void)hipMemsetAsync(P->ws->d_pack.p, 0, sizeof(int), P->ws->stream);
+    pending_release(P);
+}
+
+// roll a shard back to n_rows (multi.hip: an append that failed on a later shard).  Slots beyond n_rows keep stale data:
+// every kernel masks by row index, and the next append rewrites them.
+int cmr_index_truncate(cmr_index_t* idx, long long n_rows) {
+    if (!idx) return fail(CMR_ERR_INVALID, "NULL index");
+    std::unique_lock<std::shared_mutex> lk(idx->mu);
+    if (n_rows < 0 || n_rows > idx->n) return fail(CMR_ERR_INVALID, "truncate to %lld rows of %lld", n_rows, idx->n);
+    idx->n = n_rows;
+    return CMR_OK;
+}
+
+extern "C" {
+
+static int32_t host_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
+                           float* out_min, float* out_max, const float* min_score) {
+    if (!idx || !q || !out_ids || !out_scores) return fail(CMR_ERR_INVALID, "NULL argument");
+    CmrPending* p = nullptr;
+    int rc = cmr_index_search_begin(idx, q, nq, k, min_score, true, &p);
+    if (rc) return rc;
+    return cmr_index_search_finish(p, out_ids, out_scores, out_min, out_max);
 }
 
 int32_t cmr_index_search(cmr_index_t* idx, const float* q, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,

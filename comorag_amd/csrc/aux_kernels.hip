@@ -240,7 +240,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
                                                                     const float2* __restrict__ mm, long long id_base,
                                                                     int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                                                     float* __restrict__ out_min, float* __restrict__ out_max,
-                                                                    u64* __restrict__ out_tau) {
+                                                                    u64* __restrict__ out_tau, int grouped) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     u64* cand = reinterpret_cast<u64*>(sm);                 // k
     u64* res = cand + k;                                    // k
@@ -250,7 +250,14 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
     int* hist = wsum + MERGE_WAVES;                         // 256
     int* sel = hist + 256;                                  // 4
     float* red = reinterpret_cast<float*>(sel + 4);         // 2*MERGE_WAVES
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // query-split scans keep one [W][nq_stride] array set per query group: output query blockIdx.x is query q of group g
+    const int g = grouped ? blockIdx.x / nq_stride : 0;
+    const int q = blockIdx.x - g * nq_stride;
+    lists += (size_t)g * W * nq_stride * cap;
+    cnt += (size_t)g * W * nq_stride;
+    if (mm) mm += (size_t)g * W * nq_stride;
+    const int qo = blockIdx.x;                              // where the query's results go
 
     // exclusive prefix sum of the W list lengths
     const int CH = (W + MERGE_THREADS - 1) / MERGE_THREADS;
@@ -320,13 +327,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
     } while (base < total);
 
     if (out_tau) {
-        if (tid == 0) out_tau[q] = res[k - 1] ? res[k - 1] - 1 : 0ull;
+        if (tid == 0) out_tau[qo] = res[k - 1] ? res[k - 1] - 1 : 0ull;
         return;
     }
     for (int i = tid; i < k; i += MERGE_THREADS) {
         const u64 key = res[i];
-        out_ids[(size_t)q * k + i] = key ? (int64_t)cmr_key_row(key) + id_base : -1;
-        out_scores[(size_t)q * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
+        out_ids[(size_t)qo * k + i] = key ? (int64_t)cmr_key_row(key) + id_base : -1;
+        out_scores[(size_t)qo * k + i] = key ? cmr_key_score(key) : -__builtin_inff();
     }
     if (out_min || out_max) {
         float mn = __builtin_inff(), mx = -__builtin_inff();
@@ -340,15 +347,15 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_query_kernel(const u64* _
         __syncthreads();
         if (tid == 0) {
             for (int w2 = 1; w2 < MERGE_WAVES; ++w2) { mn = fminf(mn, red[w2]); mx = fmaxf(mx, red[MERGE_WAVES + w2]); }
-            if (out_min) out_min[q] = mn;
-            if (out_max) out_max[q] = mx;
+            if (out_min) out_min[qo] = mn;
+            if (out_max) out_max[qo] = mx;
         }
     }
 }
 
 hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
-                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s) {
+                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s, bool grouped) {
     if (W > 16 * 256) return hipErrorInvalidValue;
     // a handful of queries over more than a thousand lists (a synchronous call's main pass): the 1024-thread shape
     const bool big = nq <= 8 && W > 1024;
@@ -357,7 +364,7 @@ hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int n
     auto launch = [&](auto kern, int threads) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);     // a constant: per function, not per launch
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(nq), dim3(threads), lds, s, lists, cnt, W, nq_stride, cap, k, mm, id_base, out_ids, out_scores, out_min, out_max, out_tau);
+        hipLaunchKernelGGL(kern, dim3(nq), dim3(threads), lds, s, lists, cnt, W, nq_stride, cap, k, mm, id_base, out_ids, out_scores, out_min, out_max, out_tau, grouped ? 1 : 0);
         return hipGetLastError();
     };
     if (big) return launch(merge_query_kernel<1024, 4>, 1024);

@@ -18,6 +18,7 @@ struct CmrScanGeom {
     size_t lds;     // dynamic LDS bytes
     int wide_waves; // wide kernel at 768-d: 0 = default, 4 = one wave per SIMD x 2 tiles, 8 = two waves per SIMD x 1 tile
     int wide_abl;   // development builds only (-DCMR_DEV_KNOBS): ablation variant of the wide kernel
+    int stream_default_policy;   // narrow top-k kernel: 1 = corpus loads with the default cache policy instead of non-temporal (query-split grid)
 };
 
 // max query tiles (1/2/0=unsupported) whose fragments fit LDS for this dtype/dpad
@@ -51,6 +52,9 @@ struct CmrScanArgs {
     const u64* sample_lists;
     const int* sample_cnt;
     int sample_W;
+    // narrow kernel, query-split grid: qgroups x (geom.grid) workgroups, group g scans the whole corpus for queries
+    // g*nqt*32 ..; qfrag holds qgroups*nqt tiles, lists / cnt / mm are [qgroups][W][nqt*32](..), tau_init [qgroups][nqt*32]
+    int qgroups;
 };
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
@@ -71,9 +75,10 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
                                    long long row0, void* corpus, float* shadow, int* nonfinite_flag,
                                    hipStream_t s);
 // per-wave candidate lists -> per-query top-k (ids/scores + min/max), or the sampling threshold
+// grouped = true: the lists come from a query-split scan ([group][W][nq_stride]): query q reads group q / nq_stride
 hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
-                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s);
+                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s, bool grouped = false);
 // whole search of a small corpus in one launch (nq <= 16): kind 1 = <= 32 panels, kind 2 = hierarchical (up to max_panels panels,
 // k <= 64; needs the arrival counter), 0 = not applicable.  `arrive`: a zeroed device int the launches of
 // one stream share (nullptr: single-workgroup flat path only).

@@ -45,6 +45,8 @@
 #define CMR_STREAM_POLICY ""
 #define CMR_STREAM_LOAD(p) (*(p))
 #endif
+// scan_kernel carries the policy as a template parameter (POL = 1: the policy above; 0: default policy — the query-split grid WANTS
+// the corpus lines to stay in L2 until the twins of the other query groups have read them)
 // wide kernel: 1 = all DMA pieces of a group right after its barrier, 0 = one piece per quad of blocks
 #ifndef CMR_WIDE_DMA_BURST
 #define CMR_WIDE_DMA_BURST 0
@@ -70,6 +72,7 @@ struct ScanP {
     const u64* slists;     // lists / counters of a preceding sampling pass ([sW][32][CAP]): thresholds are derived in-kernel (nq <= 8, k <= 64)
     const int* scnt;
     int sW;
+    int qgroups;           // > 1: query-split grid (see scan_kernel): gridDim.x = qgroups x virtual grid, every group has its own query tile
 };
 
 // Slow path, part 1 (inline, a handful of registers, no waits on global memory): push the keys of
@@ -151,7 +154,7 @@ __device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0
     if (need) topk_compact<CAP>(need, k, tau_key, tau_f, cnt_t, list_t, stage, lane);
 }
 
-template <int DT, int NQT, int CAP, int R, int MODE, int ASMRING>
+template <int DT, int NQT, int CAP, int R, int MODE, int ASMRING, int POL = 1>
 __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -166,13 +169,36 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     int* cnt_w = cnt_all + wave * NQ;
     u64* stage = stage_all + wave * (CAP + 2);
 
-    for (int i = tid; i < NQT * KS * 64; i += CMR_SCAN_THREADS) qf[i] = P.qfrag[i];
+    // Query-split grid (batches of more than NQ queries in ONE corpus pass): the grid is qgroups x a virtual grid; the
+    // workgroups of group g hold query tile g (queries g*NQ ..) in LDS and walk the SAME per-wave panel ranges as their
+    // twins of the other groups.  Workgroup ids go round robin over the 8 XCDs, so with a virtual grid that is a multiple of
+    // 8 the twins (ids c*8*G + g*8 + x, g = 0..G-1) sit on CUs of ONE XCD and start together: the first of them to ask for a
+    // corpus block brings it from HBM into that XCD's L2, the others hit there (a twin that is ahead waits for HBM, one that is
+    // behind runs at L2 speed and catches up) — HBM is read once per pass, the matrix work per HBM byte is G-fold.
+    int bid = blockIdx.x, grp = 0, vgrid = gridDim.x;
+    if (P.qgroups > 1) {
+        vgrid = gridDim.x / P.qgroups;
+        if ((vgrid & 7) == 0) {
+            const int span = 8 * P.qgroups, chunk = bid / span, r = bid - chunk * span;
+            grp = r >> 3;
+            bid = chunk * 8 + (r & 7);
+        } else {
+            grp = bid / vgrid;
+            bid -= grp * vgrid;
+        }
+    }
+    const int nq_g = P.nq - grp * NQ;          // queries of this group (the last group may be ragged)
+    {
+        const v4u* qsrc = P.qfrag + (size_t)grp * NQT * KS * 64;
+        for (int i = tid; i < NQT * KS * 64; i += CMR_SCAN_THREADS) qf[i] = qsrc[i];
+    }
     if (MODE == MODE_TOPK)
         for (int i = tid; i < CMR_SCAN_WAVES * NQ; i += CMR_SCAN_THREADS) cnt_all[i] = 0;
     __syncthreads();
 
-    const int W = gridDim.x * CMR_SCAN_WAVES;
-    const int gw = blockIdx.x * CMR_SCAN_WAVES + wave;
+    const int W = vgrid * CMR_SCAN_WAVES;
+    const int gw = bid * CMR_SCAN_WAVES + wave;
+    const size_t gwl = (size_t)grp * W + gw;   // this wave's row of the list / counter / min-max arrays ([group][wave])
     int p0, p1;
     if (P.sample_waves > 0) {   // sampling pass: one strided panel per wave
         p0 = (gw >> P.sample_chunk_log2) * P.sample_stride + (gw & ((1 << P.sample_chunk_log2) - 1));
@@ -190,7 +216,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     // between the two scans (21 us + its launch gap at 1 M rows) is gone.  Any valid lower bound leaves the results unchanged.
     if constexpr (MODE == MODE_TOPK && NQT == 1) {
         if (P.slists) {                          // wave-uniform
-            if (wave < P.nq) {
+            if (wave < nq_g) {
                 u64 best = 0ull;
                 for (int w = lane; w < P.sW; w += 64) {
                     // a sampling wave scans ONE panel: <= 32 keys per list, read as 16 independent 16-byte loads (a list has room
@@ -230,19 +256,19 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         tau_key[t] = 0ull;
         if (MODE == MODE_TOPK) {
             const int q = t * 32 + (lane & 31);
-            if (q >= P.nq) {                     // padding query (all-zero operand): nothing may pass
+            if (q >= nq_g) {                     // padding query (all-zero operand): nothing may pass
                 tau_key[t] = ~0ull;
                 tau_f[t] = __builtin_inff();
             } else if (NQT == 1 && P.slists) {   // derived above from the sampling pass's lists (q < nq <= 8 waves)
                 tau_key[t] = stage_all[(size_t)q * (CAP + 2) + CAP + 1];
                 if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
             } else if (P.tau_init) {             // a valid lower bound on the global k-th best key
-                tau_key[t] = P.tau_init[q];
+                tau_key[t] = P.tau_init[grp * NQ + q];
                 if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
             }
         }
     }
-    u64* list_w = (MODE == MODE_TOPK) ? P.lists + (size_t)gw * NQ * CAP : nullptr;
+    u64* list_w = (MODE == MODE_TOPK) ? P.lists + gwl * NQ * CAP : nullptr;
 
     if (p1 > p0) {
         // The ring always prefetches R blocks ahead, also past the end of this wave's range: the
@@ -267,11 +293,16 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     if constexpr ((u) < R) {                                                                               \
         if constexpr (ASMRING) {                                                                           \
             v4u slot_ = buf[(u)];                                                                        \
-            asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" CMR_STREAM_POLICY                      \
-                         : "+v"(slot_) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
+            if constexpr (POL)                                                                             \
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" CMR_STREAM_POLICY                  \
+                             : "+v"(slot_) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
+            else                                                                                           \
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3"                                    \
+                             : "+v"(slot_) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
             buf[(u)] = slot_;                                                                              \
         } else {                                                                                           \
-            buf[(u)] = CMR_STREAM_LOAD(&src[(size_t)(u) * 64]);                                            \
+            if constexpr (POL) buf[(u)] = CMR_STREAM_LOAD(&src[(size_t)(u) * 64]);                         \
+            else               buf[(u)] = src[(size_t)(u) * 64];                                           \
         }                                                                                                  \
     }
 #define CMR_RING_STEP(u)                                                                                   \
@@ -373,8 +404,8 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             const float mx = fmaxf(rmax[t], __shfl_xor(rmax[t], 32));
             if (lane < 32) {
                 const int q = t * 32 + lane;
-                P.mm[(size_t)gw * NQ + q] = make_float2(mn, mx);
-                P.cnt[(size_t)gw * NQ + q] = __hip_atomic_load(&cnt_w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                P.mm[gwl * NQ + q] = make_float2(mn, mx);
+                P.cnt[gwl * NQ + q] = __hip_atomic_load(&cnt_w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
@@ -413,6 +444,12 @@ static hipError_t launch_one(const CmrScanGeom& g, const ScanP& p, hipStream_t s
         hipLaunchKernelGGL(kern, dim3(g.grid), dim3(CMR_SCAN_THREADS), g.lds, s, p);
         return hipGetLastError();
     };
+    if constexpr (MODE == MODE_TOPK) {
+        if (g.stream_default_policy) {
+            if (g.asm_ring) return launch(scan_kernel<DT, NQT, CAP, R, MODE, 1, 0>);
+            return launch(scan_kernel<DT, NQT, CAP, R, MODE, 0, 0>);
+        }
+    }
     if (g.asm_ring) return launch(scan_kernel<DT, NQT, CAP, R, MODE, 1>);
     return launch(scan_kernel<DT, NQT, CAP, R, MODE, 0>);
 }
@@ -441,6 +478,7 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.scores = a.scores; p.ld = a.ld; p.nq = a.nq;
     p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.sample_chunk_log2 = a.sample_chunk_log2; p.tau_init = a.tau_init;
     p.slists = a.sample_lists; p.scnt = a.sample_cnt; p.sW = a.sample_W;
+    p.qgroups = a.qgroups > 1 ? a.qgroups : 1;
     return p;
 }
 
