@@ -36,8 +36,8 @@ if os.environ.get("CMR_BUILD_LIB"):          # experiment builds go to their own
 # completely — every register index is a constant only then; with the slow path inlined at two places of it, its
 # unrolled size exceeds LLVM's default limit for "#pragma unroll" (16 K) and hipcc silently keeps the loops.
 SCAN_FLAGS = ["-mllvm", "-pragma-unroll-threshold=1048576"]
-SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip", "encoder_kernels.hip"]
-HEADERS = ["cmr_device.h", "cmr_kernels.h", os.path.join("..", "..", "include", "comorag_hip.h")]
+SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip", "encoder_kernels.hip", "multi.hip"]
+HEADERS = ["cmr_device.h", "cmr_kernels.h", "cmr_internal.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 
 _KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
 
@@ -232,14 +232,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
                     "        }\n"
                     "    return any;\n"
                     "}\n")
-        for src in ("aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip", "encoder_kernels.hip"):
+        for src in ("aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip", "encoder_kernels.hip", "multi.hip"):
             o = os.path.join(tmp, src.replace(".hip", ".o"))
             _run([HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", o], cwd=tmp)
             objs.append(o)
         o = os.path.join(tmp, "ring_audit.o")
         _run([HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(tmp, "ring_audit.cpp"), "-o", o], cwd=tmp)
         objs.append(o)
-        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
+        _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl", "-lpthread"])
     n_ok = sum(audit.values())
     info = {"hash": want, "arch": ARCH, "wide_variants_audited": len(wide), "asm_ring_variants": len(audit), "asm_ring_safe": n_ok,
             "unsafe": [list(k) for k, v in sorted(audit.items()) if not v]}

@@ -332,23 +332,31 @@ class EmbeddingStore:
         return {h: idx for idx, h in enumerate(self.hash_ids)}
 
     # ------------------------------------------------------------------ device mirror
-    def device_index(self, dtype: Optional[str] = None, device: int = 0, keep_f32: bool = False):
+    def device_index(self, dtype: Optional[str] = None, device: int = 0, keep_f32: bool = False, num_shards: Optional[int] = None,
+                     devices=None):
         """The store's rows as a `DenseIndex` (built on first use, appended to afterwards).
         Row id == `hash_id_to_idx[hash_id]`.  dtype default: `global_config.index_dtype` of the
-        embedding model when present, else "f32" (the reference's arithmetic)."""
+        embedding model when present, else "f32" (the reference's arithmetic).  `num_shards` / `devices` (default:
+        `global_config.num_shards` / `.devices`): more than one shard gives a `MultiDeviceIndex` — the same rows, row-sharded
+        over the node's GPUs inside this process, same results."""
         with self._lock:
+            cfg = getattr(self.embedding_model, "global_config", None)
             if dtype is None:
-                cfg = getattr(self.embedding_model, "global_config", None)
                 dtype = getattr(cfg, "index_dtype", None) or "f32"
-            want = dict(dtype=dtype, device=device, keep_f32=keep_f32)
+            if num_shards is None:
+                num_shards = getattr(cfg, "num_shards", None)
+            if devices is None:
+                devices = getattr(cfg, "devices", None)
+            want = dict(dtype=dtype, device=device, keep_f32=keep_f32, num_shards=num_shards or 1, devices=tuple(devices) if devices else None)
             if self._index is not None and self._index_kw != want:
                 self._index.close()
                 self._index = None
             if self._index is None:
                 if self._n == 0:
                     raise ValueError("device_index() on an empty store")
-                from .index import DenseIndex
-                self._index = DenseIndex(self._mat.shape[1], dtype, device=device, capacity_hint=self._n, keep_f32=keep_f32)
+                from .multi_index import make_index
+                self._index = make_index(self._mat.shape[1], dtype, device=device, capacity_hint=self._n, keep_f32=keep_f32,
+                                         num_shards=num_shards, devices=devices, options=getattr(cfg, "index_options", None))
                 self._index.append(self._mat[:self._n])
                 self._index_kw = want
             return self._index

@@ -44,18 +44,23 @@ def patch_reference_modules(package: str = "src.comorag") -> None:
     importlib.invalidate_caches()
 
 
-def _matrix_index(mat, dtype: str, device: int) -> Optional[DenseIndex]:
+def _matrix_index(mat, dtype: str, device: int, num_shards=None, devices=None, options=None):
     mat = np.asarray(mat, dtype=np.float32)
     if mat.ndim != 2 or mat.shape[0] == 0:
         return None
-    idx = DenseIndex(mat.shape[1], dtype, device=device, capacity_hint=mat.shape[0])
+    from .multi_index import make_index
+    idx = make_index(mat.shape[1], dtype, device=device, capacity_hint=mat.shape[0], num_shards=num_shards, devices=devices, options=options)
     idx.append(mat)
     return idx
 
 
 def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_module_functions: bool = True, index_factory=None,
-            graph_factory=None, ppr_on_device: bool = True, knn_threshold_filter: bool = True):
-    """`index_factory(matrix, dtype, device) -> index` builds the HBM mirror of a host matrix (default: a `DenseIndex`
+            graph_factory=None, ppr_on_device: bool = True, knn_threshold_filter: bool = True, num_shards: Optional[int] = None,
+            devices=None):
+    """`num_shards` / `devices` (default: `global_config.num_shards` / `.devices`, i.e. one shard): more than one shard puts
+    the passage / fact / summary matrices on a `MultiDeviceIndex` — row shards over the node's GPUs driven from this one
+    process, same results (comorag_amd/multi_index.py).
+    `index_factory(matrix, dtype, device) -> index` builds the HBM mirror of a host matrix (default: a `DenseIndex`
     filled with `append`); anything with DenseIndex's `scores` / `search` / `sorted_scores` / `__len__` serves — the
     CPU-tier binding tests pass a numpy stand-in there to exercise this glue on the real reference classes without a GPU.
     `graph_factory(igraph_like, device) -> graph` likewise (default `comorag_amd.ppr.DeviceGraph.from_igraph`); it must offer
@@ -63,7 +68,10 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
     `comorag_amd.ppr.ppr_passage_scores` unless the graph object brings its own `passage_scores(index, q, phrase_w, pnw, damping)`."""
     cfg = getattr(rag, "global_config", None)
     dtype = index_dtype or getattr(cfg, "index_dtype", None) or "f32"
-    make_index = index_factory or _matrix_index
+    n_sh = num_shards if num_shards is not None else getattr(cfg, "num_shards", None)
+    devs = devices if devices is not None else getattr(cfg, "devices", None)
+    opts = getattr(cfg, "index_options", None)        # route selectors for every index built here (DenseIndex.set_option / "append_block_rows")
+    make_index = index_factory or (lambda mat, dt, dev: _matrix_index(mat, dt, dev, n_sh, devs, opts))
     lock = threading.Lock()
     orig_prepare = rag.prepare_retrieval_objects
     rag._hip = {"passage": None, "summary": None, "fact": None, "graph": None, "dtype": dtype}
@@ -192,7 +200,7 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
     return rag
 
 
-def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0, index_factory=None):
+def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0, index_factory=None, num_shards: Optional[int] = None, devices=None):
     """Rebind `MemoryPool.retrieve_similar_nodes` (utils/memory_utils.py:188-235) on ONE pool
     instance: node embeddings live in an appendable HBM index (rows = pool order; nodes added since
     the last call are encoded with the reference's own `compute_probe_note_embeddings` and appended —
@@ -219,7 +227,11 @@ def install_memory_pool(pool, index_dtype: str = "f32", device: int = 0, index_f
                 mat = np.stack([_to_np(n.embedding) for _, n in fresh])
                 mat = mat / np.maximum(np.linalg.norm(mat, axis=1, keepdims=True), 1e-12)   # cosine == dot of unit rows
                 if state["index"] is None:      # index_factory(dim, dtype, device): test seam, as in install()
-                    state["index"] = index_factory(mat.shape[1], index_dtype, device) if index_factory else DenseIndex(mat.shape[1], index_dtype, device=device)
+                    if index_factory:
+                        state["index"] = index_factory(mat.shape[1], index_dtype, device)
+                    else:
+                        from .multi_index import make_index
+                        state["index"] = make_index(mat.shape[1], index_dtype, device=device, num_shards=num_shards, devices=devices)
                 state["index"].append(mat)
                 state["rows"].extend(i for i, _ in fresh)
             if state["index"] is None:

@@ -40,6 +40,14 @@ class DenseIndex:
         for name, value in (options or {}).items():
             self.set_option(name, value)
 
+    @classmethod
+    def _borrow(cls, handle, dim: int, dtype: str, device: int, owner=None) -> "DenseIndex":
+        """A view of a cmr_index_t somebody else owns (a shard of a MultiDeviceIndex): never destroyed from here."""
+        self = cls.__new__(cls)
+        self._h, self.dim, self.dtype, self.device, self.keep_f32 = handle, int(dim), dtype, int(device), False
+        self._borrowed, self._owner = True, owner
+        return self
+
     def set_option(self, name: str, value: int) -> None:
         """Route selector (cmr_index_set_option): picks between implementations that return the same results."""
         L.check(L.lib().cmr_index_set_option(self._h, name.encode(), int(value)))
@@ -53,7 +61,8 @@ class DenseIndex:
     # -- lifetime
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
-            L.lib().cmr_index_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                L.lib().cmr_index_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -88,6 +97,11 @@ class DenseIndex:
         """rows_t: torch float32 CUDA tensor [n, dim], contiguous, on this index's device."""
         import torch
         assert rows_t.is_cuda and rows_t.dtype == torch.float32 and rows_t.is_contiguous()
+        if rows_t.device.index != self.device:
+            # the encoder may live on another GPU than the index (cfg.device vs the store's index device): a foreign
+            # device pointer must not reach cmr_index_append_dev — go through the host
+            self.append(rows_t.cpu().numpy())
+            return
         if stream is None:
             stream = torch.cuda.current_stream(rows_t.device).cuda_stream
         L.check(L.lib().cmr_index_append_dev(self._h, C.c_void_p(rows_t.data_ptr()), rows_t.shape[0], C.c_void_p(stream)))

@@ -48,6 +48,7 @@ class DeviceGraph:
         v = np.ascontiguousarray(passage_node_idxs, dtype=np.int32)
         L.check(L.lib().cmr_graph_set_passage_vertices(self._h, v.ctypes.data_as(C.c_void_p), len(v)))
         self.n_rows = len(v)
+        self.passage_vertices = v
 
     def ppr(self, reset, damping: float = 0.5, tol: float = 1e-12, max_iter: int = 200) -> np.ndarray:
         """personalized_pagerank(reset=...) over every vertex (negative / NaN reset entries count as 0)."""
@@ -90,6 +91,21 @@ def ppr_passage_scores(index, graph: DeviceGraph, query_embedding, phrase_weight
     the reset vector on the device.  `phrase_weights`: dense [n_vertices] array (only its non-zero entries are shipped)
     or a (vertices, weights) pair.  `graph.set_passage_vertices(...)` must map every row of `index`."""
     q = np.ascontiguousarray(np.asarray(query_embedding, dtype=np.float32).reshape(-1))
+    if hasattr(index, "n_shards") or not hasattr(index, "_h"):
+        # a row-sharded index (MultiDeviceIndex): its shards live on several devices, the graph on one — the N scores come to
+        # the host once (4 N bytes), the reference's own lines build the reset vector (ComoRAG.py:1034-1045: min-max, score x
+        # passage_node_weight into the passages' vertices, product in float64 as numpy 1.26 forms it), PageRank runs on the device
+        from .utils.misc_utils import min_max_normalize
+        s = index.scores(q[None, :])[0]
+        norm = min_max_normalize(s)
+        reset = np.zeros(graph.n_vertices, dtype=np.float64)
+        if phrase_weights is not None:
+            if isinstance(phrase_weights, tuple):
+                np.add.at(reset, np.asarray(phrase_weights[0], np.int64), np.asarray(phrase_weights[1], np.float64))
+            else:
+                reset += np.asarray(phrase_weights, dtype=np.float64)
+        reset[graph.passage_vertices] += norm.astype(np.float64) * float(passage_node_weight)
+        return graph.ppr(reset, damping=damping, tol=tol, max_iter=max_iter)[graph.passage_vertices]
     if phrase_weights is None:
         sv, sw = np.empty(0, np.int32), np.empty(0, np.float64)
     elif isinstance(phrase_weights, tuple):

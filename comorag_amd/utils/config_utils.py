@@ -11,8 +11,9 @@ from typing import Optional
 
 @dataclass
 class BaseConfig:
-    # reference fields (same names, same defaults)
-    embedding_model_name: str = field(default="BAAI/bge-m3", metadata={"ref": "config_utils.py:128"})
+    # reference fields (same names, same defaults: utils/config_utils.py:128-176 of the reference)
+    embedding_model_name: str = field(default="nvidia/NV-Embed-v2", metadata={"ref": "config_utils.py:128-129"})   # the reference's default (its factory
+                                                  # has no class for it and returns None, embedding_model/__init__.py:10-17: set a "bge-" model)
     embedding_batch_size: int = 32                # :132
     embedding_return_as_normalized: bool = True   # :136
     embedding_max_seq_len: int = 2048             # :140
@@ -26,6 +27,9 @@ class BaseConfig:
     # new, opt-in (reference behaviour by default)
     index_dtype: str = "f32"                      # "f32" | "bf16" | "f16": storage dtype of the HBM index
     device: int = 0
+    num_shards: int = 1                           # > 1: the HBM indexes are row-sharded over that many shards in THIS process (MultiDeviceIndex)
+    devices: Optional[list] = None                # GPU of every shard (a device may repeat: logical shards); None = round the visible devices
+    index_options: Optional[dict] = None          # route selectors for the HBM indexes (cmr_index_set_option names; "append_block_rows" for sharded ones)
     store_format: str = "parquet"                 # "parquet" (reference behaviour) | "sidecar" (append-only files)
     embedding_cache_enabled: bool = False         # probed with hasattr by the reference (BGEEmbedding.py:57-61)
     embedding_cache_path: Optional[str] = None

@@ -264,6 +264,57 @@ int32_t cmr_comm_info(cmr_comm_t* comm, int32_t* world, int32_t* rank, int32_t* 
 int32_t cmr_comm_allgather_merge(cmr_comm_t* comm, const int64_t* ids_dev, const float* scores_dev, int32_t nq, int32_t k,
                                  int64_t* out_ids_dev, float* out_scores_dev, void* stream);
 
+/* ---- one process, several devices --------------------------------------------------------------
+ * ComoRAG runs ONE process whose 16-thread pool (ComoRAG.try_answer, ComoRAG.py:432-453) calls tri_retrieve (:456-554) at
+ * LLM-dependent times; a row-sharded index it can sit on must therefore be driven from one process.  cmr_mindex_t owns
+ * n_shards cmr_index_t row shards, shard s on device device_ids[s] (a device may appear several times: logical shards — how a
+ * 1-GPU box rehearses the layout).  Same conventions as cmr_index_t: thread-safe (searches concurrent, append exclusive), host
+ * buffers in / out, exported tie rule, global row ids dense in append order (embedding_store.py:122-128,
+ * utils/memory_utils.py:294-300) — results are identical to ONE cmr_index_t holding the same rows.
+ *   append      rows go to the shards in blocks: a block opens on the currently shortest shard and holds
+ *               max(append_block_rows, ceil(n / n_shards)) rows — a bulk append lands as contiguous row blocks, a memory pool's
+ *               25-row appends fill blocks of append_block_rows (default 65536: a corpus of a few thousand rows lives on ONE shard
+ *               and is searched without multi-shard overhead) that go round the shards; each shard translates
+ *               its rows through its block table (cmr_index_set_id_blocks).  All or nothing: a chunk that fails (NaN/Inf rows,
+ *               out of memory) rolls the shards that already took theirs back.
+ *   search      begins on every non-empty shard before it finishes on any (from three shards on the per-shard enqueues are
+ *               issued by per-shard worker threads); every shard's merge kernel writes its [nq, k] candidates straight into
+ *               pinned, device-mapped HOST memory (nq * k * 12 bytes per shard over PCIe: no peer access, no collective), the
+ *               host does the final merge of the sorted lists — north_star's "host-side final merge"; min / max combine.
+ *   scores / sorted_scores / rescore / get_rows   as on cmr_index_t, over global ids.
+ *   search_pipelined + collect   throughput mode: q_dev[s] = the batch's queries on shard s's device (entries of empty shards are
+ *               ignored); returns at once with a ticket, up to four tickets may be uncollected; collect waits for the shards,
+ *               merges on the host and frees the ticket.  k <= CMR_MAX_K.
+ *   set_option  "append_block_rows", "parallel_min_shards" (default 3), anything else goes to every shard (cmr_index_set_option).
+ *   shard       borrow shard s (profiling, options, tests).  Do NOT append to it or re-base it directly.
+ * cmr_mindex_plan_append is the routing rule on its own (pure host arithmetic, no device): chunks (shard, rows) for m appended
+ * rows given the shards' sizes and the open block (cur_shard, cur_room); n_chunks always returns the chunk count.            */
+typedef struct cmr_mindex cmr_mindex_t;
+int32_t cmr_mindex_create(int32_t n_shards, const int32_t* device_ids, int32_t dim, int32_t dtype, int64_t capacity_hint,
+                          uint32_t flags, cmr_mindex_t** out);
+int32_t cmr_mindex_destroy(cmr_mindex_t* m);
+int32_t cmr_mindex_size(cmr_mindex_t* m, int64_t* n_rows);
+int32_t cmr_mindex_info(cmr_mindex_t* m, int32_t* n_shards, int32_t* device_ids /*[n_shards] or NULL*/,
+                        int64_t* shard_rows /*[n_shards] or NULL*/, int64_t* device_bytes);
+int32_t cmr_mindex_shard(cmr_mindex_t* m, int32_t s, cmr_index_t** out);
+int32_t cmr_mindex_set_option(cmr_mindex_t* m, const char* name, int64_t value);
+int32_t cmr_mindex_append(cmr_mindex_t* m, const float* rows_f32, int64_t n);
+int32_t cmr_mindex_search(cmr_mindex_t* m, const float* q_f32, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
+                          float* out_min, float* out_max);
+int32_t cmr_mindex_search_min_score(cmr_mindex_t* m, const float* q_f32, int32_t nq, int32_t k, float min_score,
+                                    int64_t* out_ids, float* out_scores);
+int32_t cmr_mindex_scores(cmr_mindex_t* m, const float* q_f32, int32_t nq, float* out, int64_t ld);
+int32_t cmr_mindex_sorted_scores(cmr_mindex_t* m, const float* q_f32, int32_t nq, int64_t* out_ids, float* out_scores,
+                                 float* out_min, float* out_max);
+int32_t cmr_mindex_rescore(cmr_mindex_t* m, const float* q_f32, int32_t nq, const int64_t* cand, int32_t n_cand, int32_t k,
+                           int64_t* out_ids, float* out_scores);
+int32_t cmr_mindex_get_rows(cmr_mindex_t* m, const int64_t* ids, int64_t n, float* out);
+int32_t cmr_mindex_search_pipelined(cmr_mindex_t* m, const float* const* q_dev /*[n_shards]*/, int32_t nq, int32_t k, void** ticket);
+int32_t cmr_mindex_collect(cmr_mindex_t* m, void* ticket, int64_t* out_ids, float* out_scores, float* out_min, float* out_max);
+int32_t cmr_mindex_plan_append(const int64_t* shard_rows, int32_t n_shards, int32_t cur_shard, int64_t cur_room, int64_t m,
+                               int64_t block_rows, int32_t max_chunks, int32_t* out_shard, int64_t* out_count, int32_t* n_chunks,
+                               int32_t* new_cur, int64_t* new_room);
+
 /* ---- encoder tail -----------------------------------------------------------------------
  * Fused masked mean-pool + L2-normalise of the encoder's last hidden state; replaces
  * mean_pooling (embedding_model/BGEEmbedding.py:15-28) + F.normalize (:126-127, eps 1e-12).

@@ -156,13 +156,12 @@ def _exact_on(ids, q32, blocks_bf16, blk):
     return rows.astype(np.float64) @ q32.astype(np.float64)
 
 
-def test_headline_config_pipelined_vs_host_oracle():
-    """The configuration bench.py times — 10 M x 768 bf16 rows, batch 64, k = 20, cmr_index_search_pipelined (narrow
-    kernel, sampling thresholds, reserved CUs) — against an oracle at FULL size: host fp32 GEMM over the bf16-rounded
-    corpus copied back from the device, fp64 arbitration of the candidates.  Also: pipelined == synchronous, bit for bit."""
+@pytest.fixture(scope="module")
+def ten_million():
+    """10 M x 768 bf16 rows in HBM + their bf16-rounded host copy (the oracle's input): built once for the full-size tests."""
     import torch
     from comorag_amd.index import DenseIndex
-    rows, dim, B, k, blk = 10_000_000, 768, 64, 20, 250_000
+    rows, dim, blk = 10_000_000, 768, 250_000
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(20260925)
     idx = DenseIndex(dim, "bf16", capacity_hint=rows)
@@ -172,6 +171,37 @@ def test_headline_config_pipelined_vs_host_oracle():
         x = (x / x.norm(dim=1, keepdim=True)).contiguous()
         idx.append_dev(x)
         host.append(x.to(torch.bfloat16).cpu())                  # RN-even, as the index rounds
+    yield idx, host, g, blk
+    idx.close()
+
+
+def _check_against_host_oracle(ids, sc, qr, host, blk, k, rows):
+    """ids / scores [B, k] of the HIP index vs the host fp32 GEMM over the bf16-rounded rows, fp64 arbitration."""
+    B = len(qr)
+    pool, n = _host_oracle_topk(qr, host, k)
+    assert n == rows
+    for i in range(B):
+        cand = np.union1d(pool[i], ids[i])
+        ex = _exact_on(cand, qr[i], host, blk)
+        order = np.lexsort((cand, -ex))[:k]
+        exact_full = {int(c): float(e) for c, e in zip(cand, ex)}
+        ref = cand[order]
+        if not np.array_equal(ids[i], ref):                       # only near-ties inside the fp32 accumulation bound may differ
+            for a, b in zip(ids[i], ref):
+                assert a == b or abs(exact_full[int(a)] - exact_full[int(b)]) < 4e-6, (i, a, b)
+            assert abs(min(exact_full[int(a)] for a in ids[i]) - ex[order][-1]) < 4e-6
+        np.testing.assert_allclose(sc[i], [exact_full[int(a)] for a in ids[i]], atol=4e-6)
+        assert np.all(np.diff(sc[i]) <= 0)
+
+
+def test_headline_config_pipelined_vs_host_oracle(ten_million):
+    """The configuration bench.py times — 10 M x 768 bf16 rows, batch 64, k = 20, cmr_index_search_pipelined (narrow
+    kernel, sampling thresholds, reserved CUs) — against an oracle at FULL size: host fp32 GEMM over the bf16-rounded
+    corpus copied back from the device, fp64 arbitration of the candidates.  Also: pipelined == synchronous, bit for bit."""
+    import torch
+    idx, host, g, blk = ten_million
+    rows, dim, B, k = 10_000_000, 768, 64, 20
+    dev = torch.device("cuda", 0)
     q = torch.randn((B, dim), generator=g, device=dev)
     q[:8] = torch.stack([host[5 * i][77 + i].float().to(dev) for i in range(8)]) + 0.02 * q[:8]     # planted neighbours
     q = (q / q.norm(dim=1, keepdim=True)).contiguous()
@@ -189,23 +219,55 @@ def test_headline_config_pipelined_vs_host_oracle():
     sid, ssc, smn, smx = idx.search(qh, k)                                          # synchronous host API
     assert np.array_equal(ids, sid) and np.array_equal(sc, ssc) and np.array_equal(mn, smn) and np.array_equal(mx, smx)
     assert not idx.query_status()
-    idx.close()
     qr = q.to(torch.bfloat16).float().cpu().numpy()                                 # queries are rounded to the index dtype
-    pool, n = _host_oracle_topk(qr, host, k)
-    assert n == rows
-    for i in range(B):
-        cand = np.union1d(pool[i], ids[i])
-        ex = _exact_on(cand, qr[i], host, blk)
-        order = np.lexsort((cand, -ex))[:k]
-        exact_full = {int(c): float(e) for c, e in zip(cand, ex)}
-        ref = cand[order]
-        if not np.array_equal(ids[i], ref):                       # only near-ties inside the fp32 accumulation bound may differ
-            for a, b in zip(ids[i], ref):
-                assert a == b or abs(exact_full[int(a)] - exact_full[int(b)]) < 4e-6, (i, a, b)
-            assert abs(min(exact_full[int(a)] for a in ids[i]) - ex[order][-1]) < 4e-6
-        np.testing.assert_allclose(sc[i], [exact_full[int(a)] for a in ids[i]], atol=4e-6)
-        assert np.all(np.diff(sc[i]) <= 0)
+    _check_against_host_oracle(ids, sc, qr, host, blk, k, rows)
     assert np.all(sc[:8, 0] > 0.8) and [int(ids[i, 0]) for i in range(8)] == [5 * i * blk + 77 + i for i in range(8)]
+    assert np.all(mx == sc[:, 0])
+
+
+@pytest.mark.timeout(900)
+def test_config3_batch256_wide_pass_vs_narrow_passes_and_host_oracle(ten_million):
+    """BASELINE config 3's batch at FULL size on one device: 10 M x 768 bf16 rows, B = 256, k = 20, ONE corpus pass of the
+    wide kernel in pipelined mode (what bench.py's config3_batch256 row times) — bit for bit against (a) four passes of the
+    narrow kernel (scan_no_wide = 1), (b) the query-split grid of the narrow kernel (wide_mode = 2), (c) the synchronous
+    host API; and against the host oracle (fp32 GEMM over the bf16-rounded rows, fp64 arbitration) like the headline."""
+    import torch
+    idx, host, g, blk = ten_million
+    rows, dim, B, k = 10_000_000, 768, 256, 20
+    dev = torch.device("cuda", 0)
+    q = torch.randn((B, dim), generator=g, device=dev)
+    q[:8] = torch.stack([host[3 * i + 1][1234 + i].float().to(dev) for i in range(8)]) + 0.02 * q[:8]     # planted neighbours
+    q[200] = host[39][249_999].float().to(dev)                                                           # the corpus' last row, exactly
+    q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+
+    def pipelined():
+        outs = [(torch.empty((B, k), dtype=torch.int64, device=dev), torch.empty((B, k), dtype=torch.float32, device=dev),
+                 torch.empty(B, dtype=torch.float32, device=dev), torch.empty(B, dtype=torch.float32, device=dev)) for _ in range(2)]
+        h = None
+        for i in range(3):
+            o = outs[i & 1]
+            h = idx.search_pipelined(q, k, o[0], o[1], o[2], o[3])
+        idx.sync(h); torch.cuda.synchronize()
+        a, b = [t.cpu().numpy() for t in outs[0]], [t.cpu().numpy() for t in outs[1]]
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))                     # both slots
+        return a
+
+    try:
+        wide = pipelined()
+        idx.set_option("scan_no_wide", 1)
+        narrow = pipelined()
+        idx.set_option("scan_no_wide", 0); idx.set_option("wide_mode", 2)
+        grid = pipelined()
+    finally:
+        idx.set_option("scan_no_wide", 0); idx.set_option("wide_mode", 0)
+    for x, y, z in zip(wide, narrow, grid):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    sync = idx.search(q.cpu().numpy(), k)
+    assert all(np.array_equal(x, y) for x, y in zip(wide, sync))
+    ids, sc, mn, mx = wide
+    qr = q.to(torch.bfloat16).float().cpu().numpy()
+    _check_against_host_oracle(ids, sc, qr, host, blk, k, rows)
+    assert [int(ids[i, 0]) for i in range(8)] == [(3 * i + 1) * blk + 1234 + i for i in range(8)] and int(ids[200, 0]) == rows - 1
     assert np.all(mx == sc[:, 0])
 
 
