@@ -14,6 +14,10 @@ Step      = one batch of B queries against the whole (row-sharded) corpus: query
 Workload  = north_star's quoted target: 10 M x 768 bf16 rows, B=64, k=20, total corpus FIXED as N grows (strong
             scaling; rank r holds rows [r*10M/N, (r+1)*10M/N)).  BASELINE config 3 as written (the same corpus, batch
             256) is timed too at every N ("config3_batch256"); BASELINE config 2 (1 M rows) and the other extras at N=1.
+`--single-process --gpus N` times the SAME workload on the index the drop-in API builds for `global_config.num_shards = N`: one
+process, N devices (`comorag_amd.multi_index.MultiDeviceIndex` — per-shard worker threads enqueue, every shard's merge kernel
+writes its candidates into mapped host memory, host-side final merge); under a launcher with N > 1 ranks, rank 0 runs that leg
+in a child process after the one-rank-per-GPU measurement and reports it as `single_process` in the same JSON line.
 After the timed loop the LAST pipelined batch is compared with a synchronous search of the same batch (must be
 bit-identical), and recall@k against the fp32 CPU ranking is computed from THOSE ids.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event time of the scan kernel on
@@ -64,6 +68,10 @@ def parse():
     ap.add_argument("--index-option", action="append", default=[], metavar="NAME=VALUE",
                     help="route selector passed to cmr_index_set_option on this rank's index (A/B runs; DESIGN.md appendix)")
     ap.add_argument("--only-config3", action="store_true", help="after the headline, run the batch-256 row and skip the other extras")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not re-run a few steps under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic")
+    ap.add_argument("--single-process", action="store_true", help="ONE process drives all --gpus devices through MultiDeviceIndex (what hooks.install builds for num_shards = N); no launcher, no collective")
+    ap.add_argument("--no-single-process-leg", action="store_true", help="N > 1 under a launcher: skip the single-process leg rank 0 runs afterwards")
+    ap.add_argument("--single-process-timeout", type=float, default=300.0)
     return ap.parse_args()
 
 
@@ -309,6 +317,152 @@ def summarise(batch, steps, dt, prof, rows_gpu, dim, dual=False):
     return out
 
 
+def single_process_main(args):
+    """`--single-process`: the whole node from ONE process — the index hooks.install / EmbeddingStore.device_index build for
+    global_config.num_shards = N.  Same workload, same JSON line; `value` = queries / s of pipelined batches whose merged
+    results were collected on the host."""
+    import torch
+    from comorag_amd import _lib as L
+    from comorag_amd.multi_index import MultiDeviceIndex
+    n = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; comorag_amd has no CPU fallback")
+    have = torch.cuda.device_count()
+    if not args.share_device and have < n:
+        raise SystemExit(f"bench.py --single-process --gpus {n}: this node shows {have} GPU(s); use --share-device for {n} logical shards on cuda:0")
+    devices = [0] * n if args.share_device else list(range(n))
+    per = (args.rows + n - 1) // n
+    mi = MultiDeviceIndex(args.dim, args.dtype, devices=devices, capacity_hint=args.rows, options={"append_block_rows": per})
+    blk = 250_000
+    for b0, x in zip(range(0, args.rows, blk), gen_rows_dev_multi(torch, args, devices, per, blk)):
+        mi.append_dev(x)
+    for d in set(devices):
+        torch.cuda.synchronize(torch.device("cuda", d))
+    for opt in args.index_option:
+        name, _, value = opt.partition("=")
+        mi.set_option(name.strip(), int(value))
+    info = L.device_info(devices[0])
+    dev0 = torch.device("cuda", devices[0])
+
+    def run(batch, steps, warmup, seed):
+        qs = make_queries(torch, max(1, args.query_batches), batch, args.dim, dev0, seed)
+        placed = [mi.place_queries(q) for q in qs]
+        inflight = []
+        for i in range(warmup):
+            mi.collect(mi.search_pipelined(placed[i % len(placed)], args.k))
+        shards = [mi.shard(s) for s in range(n)]
+        for sh in shards:
+            sh.profile(PROFILE_EVERY)
+        mi.host_profile(reset=True)
+        for d in set(devices):
+            torch.cuda.synchronize(torch.device("cuda", d))
+        t_collect = t_enq = 0.0
+        last = None
+        t0 = time.perf_counter()
+        for i in range(steps):
+            te = time.perf_counter()
+            inflight.append(mi.search_pipelined(placed[i % len(placed)], args.k))
+            t_enq += time.perf_counter() - te
+            if len(inflight) > 2:                      # two batches stay in flight behind the one being merged
+                tc = time.perf_counter()
+                last = mi.collect(inflight.pop(0))
+                t_collect += time.perf_counter() - tc
+        while inflight:
+            last = mi.collect(inflight.pop(0))
+        for d in set(devices):
+            torch.cuda.synchronize(torch.device("cuda", d))
+        dt = time.perf_counter() - t0
+        hp = mi.host_profile(reset=True)
+        profs = []
+        for sh in shards:
+            sh.profile(False)
+            profs.append(sh.profile_collect())
+        qi = (steps - 1) % len(qs)
+        sid, ssc = mi.search(qs[qi].cpu().numpy(), args.k, with_minmax=False)[:2]
+        same = bool(np.array_equal(last[0], sid) and np.array_equal(last[1], ssc))
+        kms = [p["total_ms"] / max(p["launches"], 1) for p in profs]
+        by = max(p["bytes_per_launch"] for p in profs)
+        dual = bool(shards[0].get_option("pipe_dual_scan_active" if batch <= 64 else "pipe_dual_scan_wide_active"))
+        step_ms = dt / steps * 1e3
+        row = {"value": batch * steps / dt, "unit": "queries/s", "batch": batch, "ms_per_step": step_ms, "two_scan_streams": dual,
+               "kernel_ms_per_shard" if not dual else "kernel_lifetime_ms_per_shard": kms,
+               "hbm_GBps_per_device_step": by / (step_ms * 1e-3) / 1e9, "frac_step_of_8TBps_per_device": by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+               "host_collect_ms_per_step": t_collect / max(steps - 2, 1) * 1e3, "caller_enqueue_us_per_step": t_enq / steps * 1e6, "algorithmic_bytes_per_launch": by,
+               "host_side": hp, "last_pipelined_batch_equals_synchronous_search": same}
+        if not dual:
+            row["frac_of_8TBps_kernel"] = by / (max(kms) * 1e-3) / 1e9 / HBM_PEAK_GBS if max(kms) else 0.0
+        return row, qs, last
+
+    head, qs, last = run(args.batch, args.steps, args.warmup, 4321)
+    out = {"metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} (north_star target config; corpus fixed, "
+                                  f"row-sharded over {n} device(s) driven from ONE process)",
+                      "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "process_model": f"one process, {n} shard(s) on devices {devices} (MultiDeviceIndex)",
+                      "sharding": f"rows/{n}", "shard_rows": mi.shard_rows(), "device": info["name"], "n_cu": info["n_cu"],
+                      "exchange": "host-mapped: every shard's merge kernel writes its [B, k] candidates into pinned host memory, host-side final merge (no collective)"},
+           "roofline": {"bound": "hbm", "achieved": head["hbm_GBps_per_device_step"] if head["two_scan_streams"] else head["algorithmic_bytes_per_launch"] / (max(head["kernel_ms_per_shard"]) * 1e-3) / 1e9,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "scan_kernel (fused MFMA scan + top-k), per device",
+                        "achieved_is": "algorithmic bytes / step time" if head["two_scan_streams"] else "algorithmic bytes / HIP-event time of the slowest shard's scan",
+                        "algorithmic_bytes_per_launch": head["algorithmic_bytes_per_launch"], "rows_per_gpu": max(mi.shard_rows())},
+           "verified": {"last_pipelined_batch_equals_synchronous_search": head["last_pipelined_batch_equals_synchronous_search"]},
+           "cpu_baseline": None, "single_process": True, "headline_detail": head}
+    out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+    ok = head["last_pipelined_batch_equals_synchronous_search"]
+    if not args.no_extra and args.batch != 256 and args.dim in (768, 1024):
+        c3, _, _ = run(256, max(10, args.steps // 2), 3, 8765)
+        out["extra"] = {"config3_batch256": c3}
+        out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] = c3["last_pipelined_batch_equals_synchronous_search"]
+        ok = ok and c3["last_pipelined_batch_equals_synchronous_search"]
+    mi.close()
+    print(json.dumps(out), flush=True)
+    if not ok:
+        raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
+
+
+def gen_rows_dev_multi(torch, args, devices, per, blk):
+    """The bench corpus block by block, every block generated ON the device whose shard takes (most of) it."""
+    for b0 in range(0, args.rows, blk):
+        dev = torch.device("cuda", devices[min(len(devices) - 1, b0 // per)])
+        for x in gen_rows_dev(torch, b0, min(b0 + blk, args.rows), args.dim, dev, block=blk):
+            yield x
+
+
+def single_process_leg(args):
+    """N > 1 under a launcher, rank 0, after the one-rank-per-GPU measurement: the same workload through the single-process
+    index in a CHILD process (own HIP context; a hang is cut off by the timeout and reported, never inherited)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process", "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--k", str(args.k), "--dtype", args.dtype,
+           "--query-batches", str(args.query_batches)]
+    if args.share_device:
+        cmd.append("--share-device")
+    if args.no_extra:
+        cmd.append("--no-extra")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
+                                                             "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        try:
+            so, se = p.communicate(timeout=args.single_process_timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()                                   # this exact child
+            p.communicate()
+            return {"error": f"timeout after {args.single_process_timeout:.0f} s"}
+        lines = [l for l in so.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": f"exit code {p.returncode}", "stderr_tail": se[-600:]}
+        d = json.loads(lines[-1])
+        keep = {k_: d.get(k_) for k_ in ("value", "ms_per_step", "verified", "headline_detail")}
+        keep["process_model"] = d["config"]["process_model"]
+        keep["exchange"] = d["config"]["exchange"]
+        keep["config3_batch256"] = (d.get("extra") or {}).get("config3_batch256")
+        keep["wall_seconds"] = time.perf_counter() - t0
+        return keep
+    except Exception as e:      # the headline line must still print
+        return {"error": repr(e)[:300]}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import torch
@@ -331,6 +485,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.single_process:
+        return single_process_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     import torch
@@ -439,20 +595,43 @@ def main():
         box = [None] * world
         dist.all_gather_object(box, mine)
         out["per_rank"] = box
-    for prof_file in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json"):
-        prof_file = os.path.join(ROOT, "profiles", prof_file)
-        if os.path.exists(prof_file):
-            pj = json.load(open(prof_file))
-            w = pj.get("workload", {})
-            if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (len(sh), args.dim, args.dtype, args.batch, args.k):
-                out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = (f"profiles/{os.path.basename(prof_file)}: a committed measurement of this command (rocprofv3 --pmc FETCH_SIZE / "
-                                                     "WRITE_SIZE passes, FETCH x2 gfx950 correction), not of this run")
-                break
+    rows_here = len(sh)
     if world > 1 and c3 and shw is not sh:
         shw.close()
     sh.close()
     del sh
+    # roofline.traffic: HBM bytes per launch of the scan kernel from the PMC counters, measured BY THIS RUN — the shard is freed,
+    # bench.py re-runs itself for a few steps under rocprofv3 (FETCH_SIZE and WRITE_SIZE passes, tools/pmc_traffic.py); the
+    # committed measurement of an earlier round is only the fallback when rocprofv3 is missing or a pass fails
+    if rank == 0 and world == 1 and not args.no_pmc and not args.share_device:
+        try:
+            from tools import pmc_traffic
+            torch.cuda.empty_cache()
+            argv = ["--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--k", str(args.k), "--dtype", args.dtype,
+                    "--query-batches", str(args.query_batches)] + [x for o in args.index_option for x in ("--index-option", o)]
+            tr = pmc_traffic.measure(argv)
+        except Exception as e:      # noqa: BLE001
+            tr = {"error": repr(e)[:300]}
+        if "error" not in tr:
+            out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_over_algorithmic"] = tr["traffic_bytes_per_launch"] / prof["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py itself (4 steps), FETCH x 2 (gfx950)"
+            out["roofline"]["traffic_launches"] = tr["raw"]["FETCH_SIZE"]["launches"]
+            out["roofline"]["traffic_kernel_us_under_pmc"] = tr["raw"]["FETCH_SIZE"]["avg_kernel_us"]
+            out["pmc_this_run"] = tr
+        else:
+            out["roofline"]["traffic_error"] = tr["error"][:110]
+    if out["roofline"]["traffic"] is None:
+        for prof_file in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json"):
+            prof_file = os.path.join(ROOT, "profiles", prof_file)
+            if os.path.exists(prof_file):
+                pj = json.load(open(prof_file))
+                w = pj.get("workload", {})
+                if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (rows_here, args.dim, args.dtype, args.batch, args.k):
+                    out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = (f"FALLBACK profiles/{os.path.basename(prof_file)}: a committed measurement of this command from an earlier "
+                                                         "round, NOT of this run")
+                    break
     out["cpu_baseline"] = None
     extra = {}
     if c3 is not None:
@@ -541,11 +720,31 @@ def main():
             torch.cuda.empty_cache()
     if extra:
         out["extra"] = extra
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        # the secondary numbers that matter, flat, where the driver's parser keeps them (it drops `extra`)
+        def _get(d_, *path):
+            for p_ in path:
+                d_ = d_.get(p_) if isinstance(d_, dict) else None
+            return d_
+        flat = {"config3_batch256_kernel_ms": _get(extra, "config3_batch256", "kernel_ms"), "config3_batch256_qps": _get(extra, "config3_batch256", "value"),
+                "config2_1M_rows_ms_per_step": _get(extra, f"config2_{min(args.rows, 1_000_000)}_rows_batch{args.batch}", "ms_per_step"),
+                "config2_1M_rows_qps": _get(extra, f"config2_{min(args.rows, 1_000_000)}_rows_batch{args.batch}", "value"),
+                "shard_1p25M_rows_batch256_ms_per_step": _get(extra, f"config3_one_of_8_shards_{min(args.rows, 1_250_000)}_rows_batch256", "ms_per_step"),
+                "corpus_embed_bf16_chunks_per_s": _get(extra, "corpus_embed_bf16", "value"),
+                "single_query_latency_1M_rows_us": _get(extra, "single_query_latency", "rows", str(min(args.rows, 1_000_000)))}
+        out["config"].update({f"x_{k_}": v_ for k_, v_ in flat.items() if v_ is not None})
     if world > 1:
+        # every rank has freed its shard; the ranks leave the group BEFORE rank 0 starts the single-process leg, so that no
+        # collective is pending while ONE child process takes all the GPUs
+        torch.cuda.synchronize(device)
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and not args.no_single_process_leg:
+            torch.cuda.empty_cache()
+            out["single_process"] = single_process_leg(args)
+            if isinstance(out["single_process"].get("value"), float):
+                out["config"]["x_single_process_qps"] = out["single_process"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if not (same and same_w):
         raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
 

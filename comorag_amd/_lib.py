@@ -84,6 +84,7 @@ SIGNATURES = {
     "cmr_mindex_shard": (_i32, [_p, _i32, _P(_p)]),
     "cmr_mindex_set_option": (_i32, [_p, C.c_char_p, _i64]),
     "cmr_mindex_append": (_i32, [_p, _p, _i64]),
+    "cmr_mindex_append_dev": (_i32, [_p, _p, _i64, _i32, _p]),
     "cmr_mindex_search": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p]),
     "cmr_mindex_search_min_score": (_i32, [_p, _p, _i32, _i32, _f32, _p, _p]),
     "cmr_mindex_scores": (_i32, [_p, _p, _i32, _p, _i64]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "cmr_mindex_get_rows": (_i32, [_p, _p, _i64, _p]),
     "cmr_mindex_search_pipelined": (_i32, [_p, _p, _i32, _i32, _P(_p)]),
     "cmr_mindex_collect": (_i32, [_p, _p, _p, _p, _p, _p]),
+    "cmr_mindex_profile": (_i32, [_p, _i32, _P(_i64), _P(_f64), _P(_f64), _P(_f64)]),
     "cmr_mindex_plan_append": (_i32, [_p, _i32, _i32, _i64, _i64, _i64, _i32, _p, _p, _P(_i32), _P(_i32), _P(_i64)]),
     "cmr_pool_l2norm": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_encoder_embed_layernorm": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -173,6 +174,9 @@ struct cmr_mindex {
     std::mutex pipe_mu;
     PipeTicket ticket[kSlots];
     unsigned next_ticket = 0;
+    // host-side cost of the throughput mode (cmr_mindex_profile): ns spent in the shards' enqueue jobs, in collect's waits for the
+    // shards' events, and in the host merge
+    std::atomic<long long> prof_jobs{0}, prof_enqueue_ns{0}, prof_batches{0}, prof_wait_ns{0}, prof_merge_ns{0};
 };
 
 namespace {
@@ -359,10 +363,8 @@ int32_t cmr_mindex_set_option(cmr_mindex_t* m, const char* name, int64_t value) 
     return CMR_OK;
 }
 
-int32_t cmr_mindex_append(cmr_mindex_t* m, const float* rows, int64_t n) {
-    if (!m || (n > 0 && !rows)) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
-    if (n < 0) return cmr_fail(CMR_ERR_INVALID, "n < 0");
-    if (n == 0) return CMR_OK;
+// the routed, all-or-nothing append: `put(shard, first row of the chunk, rows in it)` places one chunk on one shard
+static int32_t mindex_append(cmr_mindex_t* m, int64_t n, const std::function<int(int, long long, long long)>& put) {
     std::unique_lock<std::shared_mutex> lk(m->mu);
     if (m->total + n - 1 > 0xFFFFFFFEll) return cmr_fail(CMR_ERR_UNSUPPORTED, "global row ids must stay below 2^32 - 1");
     // state to roll back to
@@ -381,7 +383,7 @@ int32_t cmr_mindex_append(cmr_mindex_t* m, const float* rows, int64_t n) {
     for (const Chunk& c : plan) {
         const int s = c.shard;
         const long long local_at = m->rows[s], gid = m->total;
-        rc = cmr_index_append(m->shard[s], rows + (size_t)at * m->dim, c.n);
+        rc = put(s, at, c.n);
         if (rc) { const char* e = cmr_last_error(); err = e ? e : ""; break; }
         touched[s] = 1;
         auto& l = m->blk_local[s];
@@ -415,6 +417,37 @@ int32_t cmr_mindex_append(cmr_mindex_t* m, const float* rows, int64_t n) {
     m->cur = cur;
     m->room = room;
     return CMR_OK;
+}
+
+int32_t cmr_mindex_append(cmr_mindex_t* m, const float* rows, int64_t n) {
+    if (!m || (n > 0 && !rows)) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
+    if (n < 0) return cmr_fail(CMR_ERR_INVALID, "n < 0");
+    if (n == 0) return CMR_OK;
+    return mindex_append(m, n, [&](int s, long long at, long long cnt) { return cmr_index_append(m->shard[s], rows + (size_t)at * m->dim, cnt); });
+}
+
+int32_t cmr_mindex_append_dev(cmr_mindex_t* m, const float* rows_dev, int64_t n, int32_t src_device, void* stream) {
+    if (!m || (n > 0 && !rows_dev)) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
+    if (n < 0) return cmr_fail(CMR_ERR_INVALID, "n < 0");
+    if (n == 0) return CMR_OK;
+    bool synced = false;
+    return mindex_append(m, n, [&](int s, long long at, long long cnt) -> int {
+        const float* src = rows_dev + (size_t)at * m->dim;
+        if (m->device[s] == src_device) return cmr_index_append_dev(m->shard[s], src, cnt, stream);
+        // the chunk's shard lives on another GPU: device-to-device copy into a staging buffer there (hipMemcpyPeer goes over
+        // xGMI where the devices are peers and through the host where they are not), then a local append
+        if (!synced) { M_HIP_TRY(hipSetDevice(src_device)); M_HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); synced = true; }
+        M_HIP_TRY(hipSetDevice(m->device[s]));
+        void* stage = nullptr;
+        const size_t bytes = (size_t)cnt * m->dim * 4;
+        M_HIP_TRY(hipMalloc(&stage, bytes));
+        hipError_t e = hipMemcpyPeer(stage, m->device[s], src, src_device, bytes);
+        int rc = e == hipSuccess ? cmr_index_append_dev(m->shard[s], (const float*)stage, cnt, nullptr)
+                                 : cmr_fail(CMR_ERR_HIP, "hipMemcpyPeer %d -> %d: %s", src_device, m->device[s], hipGetErrorString(e));
+        (void)hipSetDevice(m->device[s]);
+        (void)hipFree(stage);
+        return rc;
+    });
 }
 
 static int32_t mindex_search(cmr_mindex_t* m, const float* q, int32_t nq, int32_t k, const float* min_score, int64_t* out_ids, float* out_scores,
@@ -640,6 +673,8 @@ int32_t cmr_mindex_search_pipelined(cmr_mindex_t* m, const float* const* q_dev, 
         void** done = &t.done[a];
         const int dev = m->device[s];
         j.fn = [=]() -> int {
+            const auto t0 = std::chrono::steady_clock::now();
+            struct Tick { cmr_mindex* m; std::chrono::steady_clock::time_point t0; ~Tick() { m->prof_enqueue_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++m->prof_jobs; } } tick{m, t0};
             // the device's view of the pinned buffer (the same address under unified addressing; asked for, not assumed)
             hipError_t e = hipSetDevice(dev);
             if (e != hipSuccess) return cmr_fail(CMR_ERR_HIP, "hipSetDevice(%d): %s", dev, hipGetErrorString(e));
@@ -660,6 +695,7 @@ int32_t cmr_mindex_collect(cmr_mindex_t* m, void* ticket, int64_t* out_ids, floa
     if (!m || !ticket || !out_ids || !out_scores) return cmr_fail(CMR_ERR_INVALID, "NULL argument");
     PipeTicket* t = (PipeTicket*)ticket;
     if (t < m->ticket || t >= m->ticket + kSlots || !t->busy) return cmr_fail(CMR_ERR_INVALID, "not an outstanding ticket of this index");
+    const auto tw0 = std::chrono::steady_clock::now();
     t->latch.wait();                 // the shards' enqueues have been issued
     struct Free { PipeTicket* t; ~Free() { t->busy = false; } } fr{t};
     const int A = (int)t->active.size(), nq = t->nq, k = t->k;
@@ -676,6 +712,12 @@ int32_t cmr_mindex_collect(cmr_mindex_t* m, void* ticket, int64_t* out_ids, floa
         for (int i = 0; i < nq; ++i) { if (out_min) out_min[i] = INFINITY; if (out_max) out_max[i] = -INFINITY; }
         return CMR_OK;
     }
+    const auto tm0 = std::chrono::steady_clock::now();
+    struct Tock { cmr_mindex* m; std::chrono::steady_clock::time_point tw0, tm0; ~Tock() {
+        const auto now = std::chrono::steady_clock::now();
+        m->prof_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(tm0 - tw0).count();
+        m->prof_merge_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(now - tm0).count();
+        ++m->prof_batches; } } tock{m, tw0, tm0};
     const char* base = (const char*)t->h;
     const int64_t* ids = (const int64_t*)base;
     const float* sc = (const float*)(base + (size_t)A * nk * 8);
@@ -688,6 +730,18 @@ int32_t cmr_mindex_collect(cmr_mindex_t* m, void* ticket, int64_t* out_ids, floa
         if (out_min) out_min[i] = lo;
         if (out_max) out_max[i] = hi;
     }
+    return CMR_OK;
+}
+
+int32_t cmr_mindex_profile(cmr_mindex_t* m, int32_t reset, int64_t* n_batches, double* enqueue_us_per_shard, double* wait_us_per_batch,
+                           double* merge_us_per_batch) {
+    if (!m) return cmr_fail(CMR_ERR_INVALID, "NULL index");
+    const long long jobs = m->prof_jobs.load(), b = m->prof_batches.load();
+    if (n_batches) *n_batches = b;
+    if (enqueue_us_per_shard) *enqueue_us_per_shard = jobs ? m->prof_enqueue_ns.load() / 1e3 / jobs : 0.0;
+    if (wait_us_per_batch) *wait_us_per_batch = b ? m->prof_wait_ns.load() / 1e3 / b : 0.0;
+    if (merge_us_per_batch) *merge_us_per_batch = b ? m->prof_merge_ns.load() / 1e3 / b : 0.0;
+    if (reset) { m->prof_jobs = 0; m->prof_enqueue_ns = 0; m->prof_batches = 0; m->prof_wait_ns = 0; m->prof_merge_ns = 0; }
     return CMR_OK;
 }
 

@@ -104,9 +104,19 @@ class MultiDeviceIndex:
         L.check(L.lib().cmr_mindex_append(self._h, _ptr(rows), rows.shape[0]))
 
     def append_dev(self, rows_t, stream: Optional[int] = None) -> None:
-        """torch tensor [n, dim] (any device): rows are routed to their shards from a host copy — the shards live on
-        different devices, and an append is not the hot path of a sharded index."""
-        self.append(rows_t.detach().to("cpu").numpy())
+        """torch float32 CUDA tensor [n, dim] on ANY device (an encoder's output): chunks whose shard lives on that device
+        are appended in place, the others are copied device to device first (cmr_mindex_append_dev)."""
+        import torch
+        if not (rows_t.is_cuda and rows_t.dtype == torch.float32 and rows_t.is_contiguous()):
+            self.append(rows_t.detach().float().cpu().numpy())
+            return
+        if rows_t.shape[0] == 0:
+            return
+        if rows_t.ndim != 2 or rows_t.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n,{self.dim}], got {tuple(rows_t.shape)}")
+        if stream is None:
+            stream = torch.cuda.current_stream(rows_t.device).cuda_stream
+        L.check(L.lib().cmr_mindex_append_dev(self._h, C.c_void_p(rows_t.data_ptr()), rows_t.shape[0], rows_t.device.index, C.c_void_p(stream)))
 
     # -- search (host arrays in / out, as DenseIndex)
     def search(self, q, k: int, with_minmax: bool = True):
@@ -219,6 +229,16 @@ class MultiDeviceIndex:
         L.check(L.lib().cmr_mindex_collect(self._h, ticket, _ptr(ids), _ptr(sc), _ptr(mn) if with_minmax else None,
                                            _ptr(mx) if with_minmax else None))
         return (ids, sc, mn, mx) if with_minmax else (ids, sc)
+
+
+def _host_profile(self, reset: bool = True) -> dict:
+    """Host-side cost of the throughput mode since the last reset (cmr_mindex_profile)."""
+    n, e, w, mg = C.c_int64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+    L.check(L.lib().cmr_mindex_profile(self._h, 1 if reset else 0, C.byref(n), C.byref(e), C.byref(w), C.byref(mg)))
+    return {"batches": n.value, "enqueue_us_per_shard": e.value, "event_wait_us_per_batch": w.value, "host_merge_us_per_batch": mg.value}
+
+
+MultiDeviceIndex.host_profile = _host_profile
 
 
 def plan_append(shard_rows: Sequence[int], m: int, block_rows: int = 8192, cur: int = -1, room: int = 0):

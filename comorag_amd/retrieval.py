@@ -36,7 +36,10 @@ def full_scores(index: DenseIndex, query_embedding) -> np.ndarray:
 def dense_passage_retrieval(index: DenseIndex, query_embedding) -> Tuple[np.ndarray, np.ndarray]:
     """ComoRAG.dense_passage_retrieval (ComoRAG.py:950-967): ALL N ids by descending min-max
     normalised score + the scores in that order.  The N·D inner products come from the GPU; the
-    normalise + argsort lines are the reference's."""
+    normalise + argsort lines are the reference's.
+    Rows with EQUAL scores (duplicated chunks): below DEVICE_SORT_MIN_ROWS they come in the order of numpy's
+    `argsort(x)[::-1]` (introsort: unspecified, not stable — whatever the reference's own call yields on these scores),
+    from DEVICE_SORT_MIN_ROWS on by ascending row id (the library's exported tie rule; include/comorag_hip.h)."""
     if len(index) < DEVICE_SORT_MIN_ROWS:          # tiny corpora: the reference's own lines on GPU scores
         query_doc_scores = full_scores(index, query_embedding)
         query_doc_scores = min_max_normalize(query_doc_scores)

@@ -25,7 +25,11 @@
  *  - there is NO CPU fallback: without a visible gfx950 device every compute call fails with
  *    CMR_ERR_NO_DEVICE.
  *
- * Result order (exported tie rule): score descending, then row index ascending.  Scores on the
+ * Result order (exported tie rule): score descending, then row index ascending.  (Deviation from the reference, by
+ * necessity: ComoRAG ranks with np.argsort(scores)[::-1] (ComoRAG.py:964), numpy's default introsort — not stable, so rows with
+ * EQUAL scores, i.e. duplicated chunks, come out in an order numpy does not specify and that changes with the array around them.
+ * The Python layer runs that very line on the GPU scores for corpora below 28672 rows and takes this library's order above;
+ * tests/test_dropin_gpu.py pins both sides of the threshold.)  Scores on the
  * wire are RAW inner products; ComoRAG's min-max normalisation (utils/misc_utils.py:141-150) is
  * applied by the Python layer from out_min/out_max so its formula stays textually the
  * reference's.  Inputs must be finite (checked: CMR_ERR_NONFINITE).
@@ -299,6 +303,9 @@ int32_t cmr_mindex_info(cmr_mindex_t* m, int32_t* n_shards, int32_t* device_ids 
 int32_t cmr_mindex_shard(cmr_mindex_t* m, int32_t s, cmr_index_t** out);
 int32_t cmr_mindex_set_option(cmr_mindex_t* m, const char* name, int64_t value);
 int32_t cmr_mindex_append(cmr_mindex_t* m, const float* rows_f32, int64_t n);
+/* rows on device src_device (e.g. an encoder's output tensor; `stream` = the stream that produced them): chunks of shards on
+ * that device are appended in place, the others go device to device (hipMemcpyPeer) first.  Returns when the rows are in.  */
+int32_t cmr_mindex_append_dev(cmr_mindex_t* m, const float* rows_f32_dev, int64_t n, int32_t src_device, void* stream);
 int32_t cmr_mindex_search(cmr_mindex_t* m, const float* q_f32, int32_t nq, int32_t k, int64_t* out_ids, float* out_scores,
                           float* out_min, float* out_max);
 int32_t cmr_mindex_search_min_score(cmr_mindex_t* m, const float* q_f32, int32_t nq, int32_t k, float min_score,
@@ -311,6 +318,10 @@ int32_t cmr_mindex_rescore(cmr_mindex_t* m, const float* q_f32, int32_t nq, cons
 int32_t cmr_mindex_get_rows(cmr_mindex_t* m, const int64_t* ids, int64_t n, float* out);
 int32_t cmr_mindex_search_pipelined(cmr_mindex_t* m, const float* const* q_dev /*[n_shards]*/, int32_t nq, int32_t k, void** ticket);
 int32_t cmr_mindex_collect(cmr_mindex_t* m, void* ticket, int64_t* out_ids, float* out_scores, float* out_min, float* out_max);
+/* host-side cost of the throughput mode since the last reset: collected batches, mean microseconds a shard's enqueue job took
+ * on its worker thread, mean microseconds collect waited for the shards' events, mean microseconds of the host merge          */
+int32_t cmr_mindex_profile(cmr_mindex_t* m, int32_t reset, int64_t* n_batches, double* enqueue_us_per_shard, double* wait_us_per_batch,
+                           double* merge_us_per_batch);
 int32_t cmr_mindex_plan_append(const int64_t* shard_rows, int32_t n_shards, int32_t cur_shard, int64_t cur_room, int64_t m,
                                int64_t block_rows, int32_t max_chunks, int32_t* out_shard, int64_t* out_count, int32_t* n_chunks,
                                int32_t* new_cur, int64_t* new_room);

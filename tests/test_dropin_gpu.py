@@ -508,3 +508,42 @@ def test_rccl_exchange_path_one_rank(tmp_path):
     """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "EXCHANGE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n", [28_671, 28_672])
+def test_full_ranking_with_duplicate_rows_on_both_sides_of_the_device_sort_threshold(n):
+    """retrieval.dense_passage_retrieval ranks ALL rows (ComoRAG.py:958-966).  Below DEVICE_SORT_MIN_ROWS the reference's own
+    `np.argsort(scores)[::-1]` runs on the GPU scores; from there on the device radix sort.  Rows with EQUAL scores
+    (duplicated chunks) come out in numpy's introsort order (unspecified, not stable) in the first regime and by ascending
+    row id in the second (the exported tie rule) — the documented deviation of include/comorag_hip.h.  Pinned here: on both
+    sides every duplicate group sits together with identical scores, the ranking is a permutation that agrees with the
+    reference's own ranking up to the order INSIDE groups of equal scores, and above the threshold that order is ascending."""
+    from comorag_amd import retrieval
+    from comorag_amd.index import DenseIndex
+    assert retrieval.DEVICE_SORT_MIN_ROWS == 28_672
+    d = 128
+    X = orc.synthetic_corpus(n, d, seed=777)
+    groups = [[10, 500, 9_000, n - 1], [77, 20_000], [3, 4, 5]]
+    for g in groups:
+        for r in g[1:]:
+            X[r] = X[g[0]]
+    q = orc.synthetic_queries(1, d, seed=778)[0]
+    q = (q + 0.7 * X[10] + 0.4 * X[77]); q /= np.linalg.norm(q)
+    idx = DenseIndex(d, "f32", capacity_hint=n); idx.append(X)
+    ids, sc = retrieval.dense_passage_retrieval(idx, q)
+    ref_ids, ref_sc = orc.dense_passage_retrieval(X, q[None, :])          # the reference's lines on the host (np.dot + argsort)
+    assert sorted(ids.tolist()) == list(range(n)) and np.all(np.diff(sc) <= 0)
+    np.testing.assert_allclose(sc, ref_sc, atol=2e-6)
+    pos = np.empty(n, np.int64); pos[ids] = np.arange(n)
+    rpos = np.empty(n, np.int64); rpos[ref_ids] = np.arange(n)
+    for g in groups:
+        p = np.sort(pos[g])
+        assert np.array_equal(p, np.arange(p[0], p[0] + len(g))), g                      # the group is contiguous ...
+        assert len(set(sc[p].tolist())) == 1                                              # ... with one score
+        assert np.ptp(ref_sc[rpos[g]]) <= 2e-6                                            # (the host BLAS may round a row's copies differently)
+        if n >= retrieval.DEVICE_SORT_MIN_ROWS:
+            assert ids[p].tolist() == sorted(g)                                           # exported tie rule: ascending row id
+    # outside equal-score groups the two rankings agree (near-ties inside the fp32 rounding bound may swap)
+    ex = orc.exact_scores_f64(X, q[None, :])[0]
+    orc.assert_topk_equivalent(ids[:200], ref_ids[:200], ex, 1e-6)
+    idx.close()
