@@ -18,6 +18,7 @@ CMR_ERR_INVALID, CMR_ERR_NO_DEVICE, CMR_ERR_HIP, CMR_ERR_OOM, CMR_ERR_NONFINITE,
 CMR_F32, CMR_BF16, CMR_F16 = 0, 1, 2
 CMR_FLAG_KEEP_F32 = 1
 CMR_MAX_K = 128
+ABI_VERSION = 2        # include/comorag_hip.h: CMR_ABI_VERSION
 CMR_MAX_K_2PASS = 4096
 DTYPES = {"f32": CMR_F32, "fp32": CMR_F32, "float32": CMR_F32, "bf16": CMR_BF16, "bfloat16": CMR_BF16,
           "f16": CMR_F16, "fp16": CMR_F16, "float16": CMR_F16}
@@ -48,6 +49,7 @@ SIGNATURES = {
     "cmr_index_search": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p]),
     "cmr_index_search_min_score": (_i32, [_p, _p, _i32, _i32, _f32, _p, _p]),
     "cmr_index_search_min_score_dev": (_i32, [_p, _p, _i32, _i32, _f32, _p, _p, _p]),
+    "cmr_index_search_min_score_pipelined": (_i32, [_p, _p, _i32, _i32, _f32, _p, _p, _p, _P(_p)]),
     "cmr_index_search_dev": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p]),
     "cmr_index_search_pipelined": (_i32, [_p, _p, _i32, _i32, _p, _p, _p, _p, _p, _P(_p)]),
     "cmr_index_set_id_base": (_i32, [_p, _i64]),
@@ -96,9 +98,11 @@ SIGNATURES = {
     "cmr_mindex_profile": (_i32, [_p, _i32, _P(_i64), _P(_f64), _P(_f64), _P(_f64)]),
     "cmr_mindex_plan_append": (_i32, [_p, _i32, _i32, _i64, _i64, _i64, _i32, _p, _p, _P(_i32), _P(_i32), _P(_i64)]),
     "cmr_pool_l2norm": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
-    "cmr_encoder_embed_layernorm": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmr_encoder_embed_layernorm": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
+    "cmr_encoder_embed_layernorm_ragged": (_i32, [_i32, _p, _p, _p, _p, _p, _p, _p, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_encoder_attention": (_i32, [_i32, _p, _i32, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "cmr_encoder_add_layernorm": (_i32, [_i32, _p, _p, _p, _p, _p, _f32, _i64, _i32, _i32, _p, _p]),
+    "cmr_encoder_add_layernorm_pool": (_i32, [_i32, _p, _p, _p, _p, _p, _f32, _i32, _i32, _i32, _i32, _p, _i32, _p, _p, _p]),
     "cmr_profile_enable": (_i32, [_p, _i32]),
     "cmr_profile_collect": (_i32, [_p, _P(_i64), _P(_f64), _P(_f64)]),
 }
@@ -148,8 +152,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError = header/library drift: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if l.cmr_abi_version() != 1:
-            raise ImportError(f"ABI version mismatch: library {l.cmr_abi_version()} != binding 1")
+        if l.cmr_abi_version() != ABI_VERSION:
+            raise ImportError(f"ABI version mismatch: library {l.cmr_abi_version()} != binding {ABI_VERSION}")
         _lib = l
         return l
 

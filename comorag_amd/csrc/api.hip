@@ -758,7 +758,7 @@ int ensure_pipe(cmr_index* idx) {
 // on `sq`; main scans are serialised on `sm` (two HBM-bound scans at once only slow each other down) and leave
 // `reserve_cus` CUs free, on which the next pass's sampling scans and the merges run concurrently.
 int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, int64_t* ids_dev, float* scores_dev, float* min_dev,
-                             float* max_dev, hipEvent_t wait_event, hipEvent_t* done_event) {
+                             float* max_dev, hipEvent_t wait_event, hipEvent_t* done_event, const float* min_score = nullptr) {
     std::lock_guard<std::mutex> pl(idx->pipe_mu);
     Pipe& P = idx->pipe;
     { int rc_ = ensure_pipe(idx); if (rc_) return rc_; }
@@ -811,7 +811,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         int rc = enqueue_pass(idx, &sl->ws, sp, sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
                               (masked && !wide) ? idx->n_cu - P.scan_cus : (masked && wide) ? idx->n_cu - P.wide_cus : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr, wide && !quad, nullptr, wide && quad);
+                              max_dev ? max_dev + q0 : nullptr, wide && !quad, min_score, wide && quad);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(sl->main_done, P.sq));
         sl->used = true;
@@ -1156,6 +1156,21 @@ int32_t cmr_index_search_pipelined(cmr_index_t* idx, const float* q_dev, int32_t
     if (rc) return rc;
     hipEvent_t done = nullptr;
     rc = search_pipelined_enqueue(idx, q_dev, nq, k, ids_dev, scores_dev, min_dev, max_dev, (hipEvent_t)wait_event, &done);
+    if (done_event) *done_event = (void*)done;
+    return rc;
+}
+
+int32_t cmr_index_search_min_score_pipelined(cmr_index_t* idx, const float* q_dev, int32_t nq, int32_t k, float min_score, int64_t* ids_dev,
+                                             float* scores_dev, void* wait_event, void** done_event) {
+    if (!idx || !q_dev || !ids_dev || !scores_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (nq <= 0) return fail(CMR_ERR_INVALID, "nq must be > 0");
+    if (k <= 0 || k > CMR_MAX_K) return fail(CMR_ERR_UNSUPPORTED, "threshold search supports k in [1, %d]", CMR_MAX_K);
+    if (!(min_score == min_score)) return fail(CMR_ERR_INVALID, "min_score is NaN");
+    std::shared_lock<std::shared_mutex> lk(idx->mu);
+    int rc = set_device(idx->device);
+    if (rc) return rc;
+    hipEvent_t done = nullptr;
+    rc = search_pipelined_enqueue(idx, q_dev, nq, k, ids_dev, scores_dev, nullptr, nullptr, (hipEvent_t)wait_event, &done, &min_score);
     if (done_event) *done_event = (void*)done;
     return rc;
 }
@@ -1765,12 +1780,30 @@ int32_t cmr_encoder_add_layernorm(int32_t device_id, const void* y_dev, const vo
     return CMR_OK;
 }
 
+int32_t cmr_encoder_add_layernorm_pool(int32_t device_id, const void* y_dev, const void* bias_dev, const void* residual_dev, const void* gamma_dev,
+                                       const void* beta_dev, float eps, int32_t b, int32_t l, int32_t d, int32_t dtype, const int32_t* lens_dev,
+                                       int32_t normalize, float* partial_dev, float* out_dev, void* stream) {
+    if (!y_dev || !gamma_dev || !beta_dev || !lens_dev || !partial_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (b <= 0 || l <= 0 || d <= 0) return fail(CMR_ERR_INVALID, "b, l, d must be > 0");
+    if (l % 16 || d % 8 || d > 2048) return fail(CMR_ERR_UNSUPPORTED, "cmr_encoder_add_layernorm_pool: l must be a multiple of 16, d a multiple of 8 and <= 2048");
+    if (dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "cmr_encoder_add_layernorm_pool: dtype must be bf16 or f16");
+    if (((uintptr_t)y_dev | (uintptr_t)bias_dev | (uintptr_t)residual_dev | (uintptr_t)gamma_dev | (uintptr_t)beta_dev | (uintptr_t)partial_dev | (uintptr_t)out_dev) & 15)
+        return fail(CMR_ERR_UNSUPPORTED, "cmr_encoder_add_layernorm_pool: buffers must be 16-byte aligned");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    HIP_TRY(cmr_launch_add_layernorm_pool(y_dev, bias_dev, residual_dev, gamma_dev, beta_dev, eps, b, l, d, dtype, (const int*)lens_dev, normalize, partial_dev,
+                                          out_dev, (hipStream_t)stream));
+    return CMR_OK;
+}
+
 int32_t cmr_encoder_embed_layernorm(int32_t device_id, const int64_t* ids_dev, const int64_t* token_type_dev, const void* word_dev, const void* pos_dev,
                                     const void* type_dev, const void* gamma_dev, const void* beta_dev, float eps, int64_t rows, int32_t l, int32_t d,
-                                    int32_t vocab, int32_t n_positions, int32_t n_types, int32_t dtype, void* out_dev, void* stream) {
+                                    int32_t vocab, int32_t n_positions, int32_t n_types, int32_t position_offset, int32_t dtype, void* out_dev, void* stream) {
     if (!ids_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
     if (rows <= 0 || l <= 0 || d <= 0 || d % 4 || d > 2048) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: rows, l > 0, d a multiple of 4, d <= 2048");
-    if (vocab <= 0 || n_positions <= 0 || n_types <= 0) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: empty embedding table");
+    if (vocab <= 0 || n_positions <= 0 || n_types <= 0 || position_offset < 0) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: empty embedding table / negative position offset");
     if (dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: dtype must be bf16 or f16");
     if (((uintptr_t)word_dev | (uintptr_t)pos_dev | (uintptr_t)type_dev | (uintptr_t)gamma_dev | (uintptr_t)beta_dev | (uintptr_t)out_dev) & 7)
         return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm: buffers must be 8-byte aligned");
@@ -1779,7 +1812,25 @@ int32_t cmr_encoder_embed_layernorm(int32_t device_id, const int64_t* ids_dev, c
     rc = set_device(device_id);
     if (rc) return rc;
     HIP_TRY(cmr_launch_embed_layernorm((const long long*)ids_dev, (const long long*)token_type_dev, word_dev, pos_dev, type_dev, gamma_dev, beta_dev, eps,
-                                       rows, l, d, vocab, n_positions, n_types, dtype, out_dev, (hipStream_t)stream));
+                                       rows, l, d, vocab, n_positions, n_types, position_offset, dtype, out_dev, (hipStream_t)stream));
+    return CMR_OK;
+}
+
+int32_t cmr_encoder_embed_layernorm_ragged(int32_t device_id, const int32_t* ids32_dev, const int32_t* offsets_dev, const void* word_dev, const void* pos_dev,
+                                           const void* type_dev, const void* gamma_dev, const void* beta_dev, float eps, int32_t b, int32_t l, int32_t d,
+                                           int32_t vocab, int32_t n_positions, int32_t position_offset, int32_t dtype, void* out_dev, void* stream) {
+    if (!ids32_dev || !offsets_dev || !word_dev || !pos_dev || !type_dev || !gamma_dev || !beta_dev || !out_dev) return fail(CMR_ERR_INVALID, "NULL argument");
+    if (b <= 0 || l <= 0 || d <= 0 || d % 4 || d > 2048) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm_ragged: b, l > 0, d a multiple of 4, d <= 2048");
+    if (vocab <= 0 || n_positions <= 0 || position_offset < 0) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm_ragged: empty embedding table / negative position offset");
+    if (dtype != CMR_BF16 && dtype != CMR_F16) return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm_ragged: dtype must be bf16 or f16");
+    if (((uintptr_t)word_dev | (uintptr_t)pos_dev | (uintptr_t)type_dev | (uintptr_t)gamma_dev | (uintptr_t)beta_dev | (uintptr_t)out_dev) & 7)
+        return fail(CMR_ERR_INVALID, "cmr_encoder_embed_layernorm_ragged: buffers must be 8-byte aligned");
+    int rc = check_device(device_id);
+    if (rc) return rc;
+    rc = set_device(device_id);
+    if (rc) return rc;
+    HIP_TRY(cmr_launch_embed_layernorm_ragged((const int*)ids32_dev, (const int*)offsets_dev, word_dev, pos_dev, type_dev, gamma_dev, beta_dev, eps, (long long)b * l, l,
+                                              d, vocab, n_positions, position_offset, dtype, out_dev, (hipStream_t)stream));
     return CMR_OK;
 }
 

@@ -118,6 +118,14 @@ int cmr_pool_splits(int b, int l, int d);
 hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int b, int L, int n_heads, void* out, hipStream_t s);
 hipError_t cmr_launch_embed_layernorm(const long long* ids, const long long* tt, const void* word, const void* pos, const void* type,
                                       const void* gamma, const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos,
-                                      int n_types, int dtype, void* out, hipStream_t s);
+                                      int n_types, int pos_off, int dtype, void* out, hipStream_t s);
 hipError_t cmr_launch_add_layernorm(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps,
                                     long long rows, int d, int dtype, void* out, hipStream_t s);
+// the LAST layer's LayerNorm(y + bias + residual) with the masked mean-pool + L2-normalise of the encoder tail folded in: the
+// [b, l, d] hidden state is never written (l % 16 == 0, d % 8 == 0, d <= 2048; partial = b * (l / 16) * d floats of scratch)
+hipError_t cmr_launch_add_layernorm_pool(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, int b, int l,
+                                         int d, int dtype, const int* lens, int normalize, float* partial, float* out, hipStream_t s);
+// BertEmbeddings from RAGGED token ids (int32, sequences back to back; off[b + 1] their starts): row (s, t) of the [b, L] mini-batch
+hipError_t cmr_launch_embed_layernorm_ragged(const int* ids32, const int* off, const void* word, const void* pos, const void* type, const void* gamma,
+                                             const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos, int pos_off, int dtype,
+                                             void* out, hipStream_t s);

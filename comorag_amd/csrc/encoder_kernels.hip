@@ -366,20 +366,141 @@ __global__ __launch_bounds__(256) void add_ln16_kernel(const uint4* __restrict__
     }
 }
 
+// The LAST layer's bias + residual + LayerNorm with the encoder tail folded in (embedding_model/BGEEmbedding.py:15-28 mean_pooling,
+// :126-127 F.normalize): the layer's output [b, l, d] is never written.  A block takes 16 consecutive tokens of ONE sequence (l is a
+// multiple of 16), normalises them as add_ln16_kernel does, rounds to 16 bits (what the hidden state would have held), zeroes the
+// tokens at or behind the sequence's length and adds the 16 tokens up in a fixed order (xor tree inside a wave, waves 0..3 in
+// LDS): one fp32 partial row [d] per block, 1/16 of the bytes of the hidden state at 4 bytes instead of 2 -> an eighth of the
+// write, and nothing is read back but these partials.  Blocks that hold only padding leave at once (no loads, no partial).
+// pool_finish_kernel then adds a sequence's partials in block order, divides by the token count and L2-normalises (eps 1e-12).
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void add_ln16_pool_kernel(const uint4* __restrict__ y, const uint4* __restrict__ bias, const uint4* __restrict__ res,
+                                                            const uint4* __restrict__ gamma, const uint4* __restrict__ beta, float eps, int l, int d8,
+                                                            const int* __restrict__ lens, float* __restrict__ partial) {
+    __shared__ float red[4][16 * VPL * 8];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4, wave = threadIdx.x >> 6;
+    const int seq = blockIdx.y, t0 = blockIdx.x * 16;
+    const int len = lens[seq];
+    if (t0 >= len) return;                                          // a block of padding only
+    const long long row = (long long)seq * l + t0 + grp;
+    float v[VPL][8];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 16 + sub;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.0f;
+        if (i < d8) {
+            enc_acc8<DT>(v[j], y[row * d8 + i]);
+            if (bias) enc_acc8<DT>(v[j], bias[i]);
+            if (res) enc_acc8<DT>(v[j], res[row * d8 + i]);
+            sum += ((v[j][0] + v[j][1]) + (v[j][2] + v[j][3])) + ((v[j][4] + v[j][5]) + (v[j][6] + v[j][7]));
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float inv_d = 1.0f / (float)(8 * d8);
+    const float mean = sum * inv_d;
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j)
+        if (j * 16 + sub < d8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = v[j][e] - mean; sq = fmaf(t, t, sq); }
+        }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = rsqrtf(sq * inv_d + eps);
+    const bool live = t0 + grp < len;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 16 + sub;
+        if (i < d8) {
+            float gm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            enc_acc8<DT>(gm, gamma[i]);
+            enc_acc8<DT>(bt, beta[i]);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {      // round to 16 bits as the stored hidden state would be, then back
+                const unsigned w = enc_pack2<DT>(fmaf((v[j][e] - mean) * rstd, gm[e], bt[e]), fmaf((v[j][e + 1] - mean) * rstd, gm[e + 1], bt[e + 1]));
+                enc_unpack2<DT>(w, v[j][e], v[j][e + 1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = live ? v[j][e] : 0.0f;
+            x += __shfl_xor(x, 16);               // the wave's four tokens: a fixed tree
+            x += __shfl_xor(x, 32);
+            v[j][e] = x;
+        }
+    }
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[wave][(j * 16 + sub) * 8 + e] = v[j][e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float* dst = partial + ((size_t)seq * gridDim.x + blockIdx.x) * (size_t)(8 * d8);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int i = j * 16 + sub;
+            if (i < d8) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = ((red[0][i * 8 + e] + red[1][i * 8 + e]) + red[2][i * 8 + e]) + red[3][i * 8 + e];
+                reinterpret_cast<float4*>(dst + i * 8)[0] = make_float4(o[0], o[1], o[2], o[3]);
+                reinterpret_cast<float4*>(dst + i * 8)[1] = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+}
+
+// out[seq] = normalise(sum over the sequence's live blocks of partial / len): one block per sequence
+__global__ __launch_bounds__(256) void pool_finish_kernel(const float* __restrict__ partial, const int* __restrict__ lens, int nblk, int d, int normalize,
+                                                          float* __restrict__ out) {
+    __shared__ float wsum[4];
+    const int seq = blockIdx.x, len = lens[seq];
+    const int live = len > 0 ? (len + 15) / 16 : 0;
+    const float inv = len > 0 ? 1.0f / (float)len : 0.0f;
+    float ss = 0.0f;
+    float keep[8];                                                  // d <= 2048 = 256 threads x 8
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int f = r * 256 + threadIdx.x;
+        float s = 0.0f;
+        if (f < d)
+            for (int b = 0; b < live && b < nblk; ++b) s += partial[((size_t)seq * nblk + b) * d + f];
+        keep[r] = s * inv;
+        ss = fmaf(keep[r], keep[r], ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float norm = sqrtf((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+    const float scale = normalize ? 1.0f / fmaxf(norm, 1e-12f) : 1.0f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int f = r * 256 + threadIdx.x;
+        if (f < d) out[(size_t)seq * d + f] = keep[r] * scale;
+    }
+}
+
 // BertEmbeddings: LayerNorm(word[ids[t]] + position[t mod L] + token_type[tt[t]]), one wave per token (tt == NULL: type 0).
 // Ids outside the tables are clamped into them (PyTorch's gather would fault the device instead).
 template <int DT, int VPL>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const long long* __restrict__ ids, const long long* __restrict__ tt,
                                                        const uint2* __restrict__ word, const uint2* __restrict__ pos, const uint2* __restrict__ type,
                                                        const uint2* __restrict__ gamma, const uint2* __restrict__ beta, float eps, long long rows,
-                                                       int L, int d4, int vocab, int n_pos, int n_types, uint2* __restrict__ out) {
+                                                       int L, int d4, int vocab, int n_pos, int n_types, int pos_off, uint2* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wave;
     if (row >= rows) return;
     long long id = ids[row], ty = tt ? tt[row] : 0;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     ty = ty < 0 ? 0 : (ty >= n_types ? n_types - 1 : ty);
-    int p = (int)(row % L);
+    int p = (int)(row % L) + pos_off;      // RoBERTa-style tables start at padding_idx + 1 (right-padded rows: token t is position t + offset)
     p = p >= n_pos ? n_pos - 1 : p;
     float v[VPL][4];
     float sum = 0.0f;
@@ -395,6 +516,69 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const long long* __restri
         }
     }
     enc_ln_store<DT, VPL>(v, sum, lane, d4, gamma, beta, eps, out + row * d4);
+}
+
+// The same from RAGGED token ids: ids32 holds the sequences' tokens back to back (int32), sequence s = ids32[off[s] .. off[s + 1]);
+// row (s, t) of the [b, L] mini-batch embeds token t of sequence s, or token 0 behind the sequence's end (those rows are padding:
+// attention masks them as keys, the pooling leaves them out).  No padded id / mask / token-type tensors exist on either side of
+// the link: the host concatenates the tokenizer's output and ships lens | offsets | ids in ONE copy.  Token type 0 (one segment).
+template <int DT, int VPL>
+__global__ __launch_bounds__(256) void embed_ln_ragged_kernel(const int* __restrict__ ids32, const int* __restrict__ off, const uint2* __restrict__ word,
+                                                              const uint2* __restrict__ pos, const uint2* __restrict__ type, const uint2* __restrict__ gamma,
+                                                              const uint2* __restrict__ beta, float eps, long long rows, int L, int d4, int vocab, int n_pos,
+                                                              int pos_off, uint2* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int seq = (int)(row / L), t = (int)(row % L);
+    const int o0 = off[seq], len = off[seq + 1] - o0;
+    long long id = t < len ? ids32[o0 + t] : 0;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int p = t + pos_off;
+    p = p >= n_pos ? n_pos - 1 : p;
+    float v[VPL][4];
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int i = j * 64 + lane;
+        v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.0f;
+        if (i < d4) {
+            enc_acc4<DT>(v[j], word[id * d4 + i]);
+            enc_acc4<DT>(v[j], pos[(long long)p * d4 + i]);
+            enc_acc4<DT>(v[j], type[i]);
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    enc_ln_store<DT, VPL>(v, sum, lane, d4, gamma, beta, eps, out + row * d4);
+}
+
+template <int DT>
+static hipError_t launch_embed_ln_ragged(const int* ids32, const int* off, const void* word, const void* pos, const void* type, const void* gamma,
+                                         const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos, int pos_off, void* out, hipStream_t s) {
+    const int d4 = d / 4, vpl = (d4 + 63) / 64;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define ENC_EMBR(V)                                                                                                                       \
+    hipLaunchKernelGGL((embed_ln_ragged_kernel<DT, V>), grid, block, 0, s, ids32, off, reinterpret_cast<const uint2*>(word), reinterpret_cast<const uint2*>(pos), \
+                       reinterpret_cast<const uint2*>(type), reinterpret_cast<const uint2*>(gamma), reinterpret_cast<const uint2*>(beta), eps, rows, \
+                       L, d4, vocab, n_pos, pos_off, reinterpret_cast<uint2*>(out))
+    switch (vpl) {
+        case 1: ENC_EMBR(1); break;
+        case 2: ENC_EMBR(2); break;
+        case 3: ENC_EMBR(3); break;
+        case 4: ENC_EMBR(4); break;
+        case 5: case 6: ENC_EMBR(6); break;
+        case 7: case 8: ENC_EMBR(8); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef ENC_EMBR
+    return hipGetLastError();
+}
+
+hipError_t cmr_launch_embed_layernorm_ragged(const int* ids32, const int* off, const void* word, const void* pos, const void* type, const void* gamma,
+                                             const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos, int pos_off, int dtype,
+                                             void* out, hipStream_t s) {
+    if (dtype == CMR_DT_BF16) return launch_embed_ln_ragged<CMR_DT_BF16>(ids32, off, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, pos_off, out, s);
+    return launch_embed_ln_ragged<CMR_DT_F16>(ids32, off, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, pos_off, out, s);
 }
 
 template <int DT>
@@ -442,14 +626,14 @@ static hipError_t launch_add_ln(const void* y, const void* bias, const void* res
 
 template <int DT>
 static hipError_t launch_embed_ln(const long long* ids, const long long* tt, const void* word, const void* pos, const void* type, const void* gamma,
-                                  const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos, int n_types, void* out,
+                                  const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos, int n_types, int pos_off, void* out,
                                   hipStream_t s) {
     const int d4 = d / 4, vpl = (d4 + 63) / 64;
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
 #define ENC_EMB(V)                                                                                                                       \
     hipLaunchKernelGGL((embed_ln_kernel<DT, V>), grid, block, 0, s, ids, tt, reinterpret_cast<const uint2*>(word), reinterpret_cast<const uint2*>(pos), \
                        reinterpret_cast<const uint2*>(type), reinterpret_cast<const uint2*>(gamma), reinterpret_cast<const uint2*>(beta), eps, rows, \
-                       L, d4, vocab, n_pos, n_types, reinterpret_cast<uint2*>(out))
+                       L, d4, vocab, n_pos, n_types, pos_off, reinterpret_cast<uint2*>(out))
     switch (vpl) {
         case 1: ENC_EMB(1); break;
         case 2: ENC_EMB(2); break;
@@ -463,11 +647,45 @@ static hipError_t launch_embed_ln(const long long* ids, const long long* tt, con
     return hipGetLastError();
 }
 
+template <int DT>
+static hipError_t launch_add_ln_pool(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, int b, int l,
+                                     int d, const int* lens, int normalize, float* partial, float* out, hipStream_t s) {
+    const int d8 = d / 8, vpl16 = (d8 + 15) / 16;
+    const dim3 grid((unsigned)(l / 16), (unsigned)b), block(256);
+#define ENC_LNP(V)                                                                                                                        \
+    hipLaunchKernelGGL((add_ln16_pool_kernel<DT, V>), grid, block, 0, s, reinterpret_cast<const uint4*>(y), reinterpret_cast<const uint4*>(bias), \
+                       reinterpret_cast<const uint4*>(res), reinterpret_cast<const uint4*>(gamma), reinterpret_cast<const uint4*>(beta), eps, l, \
+                       d8, lens, partial)
+    switch (vpl16) {
+        case 1: ENC_LNP(1); break;
+        case 2: ENC_LNP(2); break;
+        case 3: case 4: ENC_LNP(4); break;
+        case 5: case 6: ENC_LNP(6); break;
+        case 7: case 8: ENC_LNP(8); break;
+        case 9: case 10: case 11: case 12: ENC_LNP(12); break;
+        case 13: case 14: case 15: case 16: ENC_LNP(16); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef ENC_LNP
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((unsigned)b), dim3(256), 0, s, partial, lens, l / 16, d, normalize, out);
+    return hipGetLastError();
+}
+
+// LayerNorm(y + bias + residual) of a [b, l, d] mini-batch folded into the masked mean-pool + L2-normalise of its rows:
+// l % 16 == 0, d % 8 == 0, d <= 2048, 16-byte aligned buffers; partial: b * (l / 16) * d floats of scratch
+hipError_t cmr_launch_add_layernorm_pool(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, int b, int l,
+                                         int d, int dtype, const int* lens, int normalize, float* partial, float* out, hipStream_t s) {
+    if (dtype == CMR_DT_BF16) return launch_add_ln_pool<CMR_DT_BF16>(y, bias, res, gamma, beta, eps, b, l, d, lens, normalize, partial, out, s);
+    return launch_add_ln_pool<CMR_DT_F16>(y, bias, res, gamma, beta, eps, b, l, d, lens, normalize, partial, out, s);
+}
+
 hipError_t cmr_launch_embed_layernorm(const long long* ids, const long long* tt, const void* word, const void* pos, const void* type,
                                       const void* gamma, const void* beta, float eps, long long rows, int L, int d, int vocab, int n_pos,
-                                      int n_types, int dtype, void* out, hipStream_t s) {
-    if (dtype == CMR_DT_BF16) return launch_embed_ln<CMR_DT_BF16>(ids, tt, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, n_types, out, s);
-    return launch_embed_ln<CMR_DT_F16>(ids, tt, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, n_types, out, s);
+                                      int n_types, int pos_off, int dtype, void* out, hipStream_t s) {
+    if (dtype == CMR_DT_BF16) return launch_embed_ln<CMR_DT_BF16>(ids, tt, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, n_types, pos_off, out, s);
+    return launch_embed_ln<CMR_DT_F16>(ids, tt, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, n_types, pos_off, out, s);
 }
 
 hipError_t cmr_launch_add_layernorm(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, long long rows,

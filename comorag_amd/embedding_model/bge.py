@@ -123,6 +123,11 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             else:
                 self.encoder_path = f"transformers ({reason})"
         self.max_positions = int(getattr(self.embedding_model.config, "max_position_embeddings", 1 << 30))
+        if getattr(self.embedding_model.config, "model_type", "") in ("roberta", "xlm-roberta", "camembert"):
+            # RoBERTa-family position ids start at padding_idx + 1: a table of 8194 rows serves sequences of 8192 tokens
+            pad = getattr(getattr(self.embedding_model, "embeddings", None), "padding_idx", None)
+            pad = getattr(self.embedding_model.config, "pad_token_id", 1) if pad is None else pad
+            self.max_positions = max(1, self.max_positions - int(pad or 0) - 1)
         import os
         # mini-batches of similar token count (sorted by length, results scattered back): a mini-batch is padded to ITS
         # longest prompt, so mixing a 40-token and a 512-token chunk wastes 92 % of the short one's forward
@@ -202,8 +207,11 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                 lens = lens_of_mask(inputs["attention_mask"].numpy())      # None unless every row is ones-then-zeros
             inputs = {k: (v if v.is_cuda else self._upload(v)) for k, v in inputs.items()}
             if lens is not None:
+                # (16-token-aligned mini-batches — what _tokenize pads to for the fused stack — take the tail inside the last
+                # layer's LayerNorm kernel; any other shape pools the stored hidden state)
                 return self._fused(inputs["input_ids"], self._upload(torch.from_numpy(lens)), token_type_ids=inputs.get("token_type_ids"),
-                                   consume=lambda hidden: pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize))
+                                   consume=lambda hidden: pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize),
+                                   pool=bool(normalize) if self._fused.can_pool(int(inputs["input_ids"].shape[1])) else None)
             hidden = self.embedding_model(**inputs).last_hidden_state
             return pool_l2norm(hidden, inputs["attention_mask"], normalize=normalize)
 

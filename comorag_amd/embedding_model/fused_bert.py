@@ -14,8 +14,8 @@ The weights are the loaded model's own tensors (query / key / value concatenated
 LayerNorm are one HIP kernel (cmr_encoder_embed_layernorm).  Results equal the transformers forward up to 16-bit rounding (the fused LayerNorm rounds once instead of
 three times): tests/test_encoder_fused_gpu.py compares both with the fp32 oracle.
 
-Used when `why_not(model)` is None: BERT architecture, absolute positions, exact GELU, 64-wide heads, bf16 / fp16 weights; any
-other model keeps the transformers forward (`HipBGEEmbeddingModel.encoder_path` says which one runs).
+Used when `why_not(model)` is None: BERT / RoBERTa / XLM-R architecture (bge-base / -large, bge-m3), absolute positions, exact GELU,
+64-wide heads, bf16 / fp16 weights; any other model keeps the transformers forward (`HipBGEEmbeddingModel.encoder_path` says which one runs).
 """
 from __future__ import annotations
 
@@ -27,12 +27,28 @@ import numpy as np
 from .. import _lib as L
 
 
+# BERT and its RoBERTa-family twins (same layer; position ids start at padding_idx + 1, one token type): XLM-R is bge-m3, the one
+# BGE model whose 8192 positions are safe with the reference's default embedding_max_seq_len = 2048 (config_utils.py:140)
+ENCODER_TYPES = ("bert", "roberta", "xlm-roberta")
+
+
+def position_offset(model) -> int:
+    """First position id of a sequence: 0 for BERT, padding_idx + 1 for the RoBERTa family
+    (transformers' RobertaEmbeddings.create_position_ids_from_input_ids)."""
+    if getattr(model.config, "model_type", "") == "bert":
+        return 0
+    pad = getattr(model.embeddings, "padding_idx", None)
+    if pad is None:
+        pad = getattr(model.config, "pad_token_id", 1)
+    return int(pad) + 1
+
+
 def why_not(model) -> Optional[str]:
     """None if the fused layer stack can run this model, else the reason it cannot."""
     import torch
     cfg = getattr(model, "config", None)
-    if cfg is None or getattr(cfg, "model_type", "") != "bert":
-        return "not a BERT encoder"
+    if cfg is None or getattr(cfg, "model_type", "") not in ENCODER_TYPES:
+        return "not a BERT / RoBERTa / XLM-R encoder"
     if not (hasattr(model, "embeddings") and hasattr(model, "encoder") and hasattr(model.encoder, "layer")
             and all(hasattr(model.embeddings, n) for n in ("word_embeddings", "position_embeddings", "token_type_embeddings", "LayerNorm"))):
         return "unexpected module layout"
@@ -78,7 +94,9 @@ class FusedBertLayers:
         emb = model.embeddings
         self.emb = tuple(t.detach().contiguous() for t in (emb.word_embeddings.weight, emb.position_embeddings.weight,
                                                            emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias))
+        self.pos_offset = position_offset(model)
         import threading
+        self.fold_pool = True                        # the encoder tail (mean-pool + L2-norm) rides the last layer's LayerNorm kernel
         self.graphs = int(graphs)                    # mini-batch shapes kept as captured hipGraphs (0: every forward is launched eagerly)
         self._graphs, self._seen, self._glock = {}, {}, threading.Lock()
         self.layers = []
@@ -115,8 +133,8 @@ class FusedBertLayers:
         L.check(L.lib().cmr_encoder_embed_layernorm(ids.device.index or 0, C.c_void_p(ids.data_ptr()), C.c_void_p(tt.data_ptr() if tt is not None else 0),
                                                     C.c_void_p(word.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(typ.data_ptr()),
                                                     C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), self.eps, b * l, l, self.hidden,
-                                                    word.shape[0], pos.shape[0], typ.shape[0], self.cmr_dtype, C.c_void_p(out.data_ptr()),
-                                                    C.c_void_p(stream)))
+                                                    word.shape[0], pos.shape[0], typ.shape[0], int(getattr(self, "pos_offset", 0)), self.cmr_dtype,
+                                                    C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
     def add_layernorm(self, y, bias, residual, gamma, beta, stream: Optional[int] = None):
@@ -130,26 +148,50 @@ class FusedBertLayers:
                                                   C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
+    def add_layernorm_pool(self, y, bias, residual, gamma, beta, lens_dev, b: int, l: int, normalize: bool = True, stream: Optional[int] = None):
+        """The last layer's add_layernorm with mean_pooling + F.normalize folded in (cmr_encoder_add_layernorm_pool): [b, hidden]
+        fp32; the [b, l, hidden] state is never written."""
+        import torch
+        out = torch.empty((b, self.hidden), dtype=torch.float32, device=y.device)
+        partial = torch.empty((b * (l // 16), self.hidden), dtype=torch.float32, device=y.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(y.device).cuda_stream
+        L.check(L.lib().cmr_encoder_add_layernorm_pool(y.device.index or 0, C.c_void_p(y.data_ptr()), C.c_void_p(bias.data_ptr() if bias is not None else 0),
+                                                       C.c_void_p(residual.data_ptr() if residual is not None else 0), C.c_void_p(gamma.data_ptr()),
+                                                       C.c_void_p(beta.data_ptr()), self.eps, b, l, self.hidden, self.cmr_dtype, C.c_void_p(lens_dev.data_ptr()),
+                                                       1 if normalize else 0, C.c_void_p(partial.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
+
+    def can_pool(self, l: int) -> bool:
+        """Can the encoder tail be folded into the last layer's LayerNorm for mini-batches of l (padded) tokens?"""
+        return self.fold_pool and l % 16 == 0 and self.hidden % 8 == 0
+
     # ------------------------------------------------------------------ forward
-    def _stack(self, input_ids, lens_dev, token_type_ids):
-        """Embeddings + every layer on torch's current stream; all arguments on the GPU."""
+    def _stack(self, input_ids, lens_dev, token_type_ids, pool=None):
+        """Embeddings + every layer on torch's current stream; all arguments on the GPU.  pool = None: the last hidden state
+        [b, l, hidden]; pool = True / False: the pooled rows [b, hidden] fp32, L2-normalised or not (the tail rides the last
+        layer's LayerNorm kernel)."""
         import torch
         import torch.nn.functional as F
         b, l = input_ids.shape
         stream = torch.cuda.current_stream(input_ids.device).cuda_stream
         x = self.embed(input_ids, token_type_ids, stream)
-        for (wqkv, bqkv, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2) in self.layers:
+        last = len(self.layers) - 1
+        for n, (wqkv, bqkv, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2) in enumerate(self.layers):
             qkv = F.linear(x, wqkv, bqkv)
             ctx = self.attention(qkv, lens_dev, b, l, stream)
             x = self.add_layernorm(F.linear(ctx, wo), bo, x, g1, be1, stream)
             h = F.gelu(F.linear(x, w1, b1))
+            if n == last and pool is not None:
+                return self.add_layernorm_pool(F.linear(h, w2), b2, x, g2, be2, lens_dev, b, l, bool(pool), stream)
             x = self.add_layernorm(F.linear(h, w2), b2, x, g2, be2, stream)
         return x.view(b, l, self.hidden)
 
-    def __call__(self, input_ids, lens: np.ndarray, token_type_ids=None, consume=None):
+    def __call__(self, input_ids, lens: np.ndarray, token_type_ids=None, consume=None, pool=None):
         """input_ids [b, l] int64 on the GPU (right-padded), lens[b] real token counts (host array, or an int32 tensor already
         on the GPU) → last hidden state [b, l, hidden];
-        with `consume`, returns consume(hidden) instead.
+        with `consume`, returns consume(hidden) instead; with pool = True / False (and `can_pool(l)`), the pooled rows [b, hidden]
+        fp32 — masked mean over the tokens, L2-normalised or not — computed inside the last layer's LayerNorm kernel.
 
         A mini-batch shape seen before runs as ONE captured hipGraph (`graphs` > 0: up to that many shapes are kept, captured at
         a shape's second occurrence): ~100 launches and as many interpreter round trips become one, which is most of a short
@@ -164,7 +206,11 @@ class FusedBertLayers:
                 lens_src = lens.to(torch.int32)              # already uploaded by the caller (its own pinned staging ring)
             else:
                 lens_src = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32)).pin_memory()
-            key = (b, l, token_type_ids is not None)
+            if pool is not None and not self.can_pool(l):
+                if consume is None:
+                    raise ValueError("FusedBertLayers: pool needs l % 16 == 0 (pass consume= for other shapes)")
+                pool = None
+            key = (b, l, token_type_ids is not None, pool)
             if self.graphs > 0:
                 with self._glock:
                     ent = self._graphs.get(key)
@@ -173,7 +219,7 @@ class FusedBertLayers:
                             self._seen.clear()
                         seen = self._seen[key] = self._seen.get(key, 0) + 1
                         if seen >= 2 and len(self._graphs) < self.graphs:
-                            ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None)
+                            ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None, pool)
                     if ent is not None:
                         cur = torch.cuda.current_stream(input_ids.device)
                         if ent.get("stream") is not None and ent["stream"] != cur:
@@ -184,11 +230,13 @@ class FusedBertLayers:
                         if token_type_ids is not None:
                             ent["tt"].copy_(token_type_ids, non_blocking=True)
                         ent["graph"].replay()
+                        if pool is not None:
+                            return ent["hidden"].clone()         # [b, hidden] fp32: the graph's static output, copied out under the lock
                         return consume(ent["hidden"]) if consume is not None else ent["hidden"].clone()
-            hidden = self._stack(input_ids, lens_src.to(input_ids.device, non_blocking=True), token_type_ids)
-            return consume(hidden) if consume is not None else hidden
+            hidden = self._stack(input_ids, lens_src.to(input_ids.device, non_blocking=True), token_type_ids, pool)
+            return hidden if pool is not None else (consume(hidden) if consume is not None else hidden)
 
-    def _capture(self, b: int, l: int, has_tt: bool):
+    def _capture(self, b: int, l: int, has_tt: bool, pool=None):
         """Static buffers + one eager pass on a side stream (allocator and GEMM-heuristic warm-up) + the captured pass."""
         import torch
         dev = self.device
@@ -198,11 +246,11 @@ class FusedBertLayers:
         side = torch.cuda.Stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            self._stack(ent["ids"], ent["lens"], ent["tt"])
+            self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"])
+            ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
         ent["graph"] = graph
         return ent
 

@@ -152,6 +152,17 @@ class DenseIndex:
                                                        C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_scores.data_ptr()), C.c_void_p(stream)))
         return out_ids, out_scores
 
+    def search_min_score_pipelined(self, q_t, k: int, min_score: float, out_ids, out_scores, wait_event=None):
+        """`search_min_score` in throughput mode (the index's own streams; packing, scan and candidate merge of consecutive blocks
+        overlap): returns the done-event handle of this block — `sync(handle)` of the LAST block covers every earlier one."""
+        import torch
+        assert q_t.is_cuda and q_t.dtype == torch.float32 and q_t.is_contiguous() and q_t.shape[1] == self.dim
+        done = C.c_void_p()
+        we = C.c_void_p(wait_event.cuda_event) if wait_event is not None else None
+        L.check(L.lib().cmr_index_search_min_score_pipelined(self._h, C.c_void_p(q_t.data_ptr()), q_t.shape[0], k, float(min_score),
+                                                             C.c_void_p(out_ids.data_ptr()), C.c_void_p(out_scores.data_ptr()), we, C.byref(done)))
+        return done
+
     def search_dev(self, q_t, k: int, out_ids=None, out_scores=None, out_min=None, out_max=None,
                    stream: Optional[int] = None):
         """Asynchronous search on torch CUDA tensors, enqueued on torch's current stream (also when that is the default

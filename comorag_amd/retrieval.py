@@ -144,9 +144,12 @@ def retrieve_knn(query_ids: Sequence[str], key_ids: Sequence[str], query_vecs, k
                 q_t = torch.from_numpy(q).to(dev)
                 ids_t = torch.empty((len(q), thr_k), dtype=torch.int64, device=dev)
                 sc_t = torch.empty((len(q), thr_k), dtype=torch.float32, device=dev)
-                for s in range(0, len(q), query_batch_size):
+                torch.cuda.synchronize(dev)                     # the uploads above are done before the index's own streams read them
+                done = None
+                for s in range(0, len(q), query_batch_size):   # throughput mode: block i + 1 is packed and block i - 1 merged beside the scan of block i
                     e = min(s + query_batch_size, len(q))
-                    index.search_min_score_dev(q_t[s:e], thr_k, min_score, ids_t[s:e], sc_t[s:e])
+                    done = index.search_min_score_pipelined(q_t[s:e], thr_k, min_score, ids_t[s:e], sc_t[s:e])
+                index.sync(done)
                 torch.cuda.synchronize(dev)
                 if index.query_status():
                     from ._lib import CMR_ERR_NONFINITE, CmrError

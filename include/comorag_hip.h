@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define CMR_ABI_VERSION 1
+#define CMR_ABI_VERSION 2
 
 enum cmr_status {
     CMR_OK = 0,
@@ -120,6 +120,11 @@ int32_t cmr_index_search_min_score(cmr_index_t* idx, const float* q_f32, int32_t
  * (queries uploaded once, results downloaded once) instead of an upload, a sync and a download per block.                 */
 int32_t cmr_index_search_min_score_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k, float min_score,
                                        int64_t* out_ids_dev, float* out_scores_dev, void* stream);
+/* The threshold search in throughput mode (as cmr_index_search_pipelined below: the index's own streams, packing of block i + 1
+ * and the candidate merge of block i - 1 run beside the scan of block i) — the synonymy self-join enqueues all its query blocks
+ * this way and waits for the last *done_event (every merge runs on one in-order stream).                                  */
+int32_t cmr_index_search_min_score_pipelined(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k, float min_score,
+                                             int64_t* out_ids_dev, float* out_scores_dev, void* wait_event, void** done_event);
 int32_t cmr_index_search_dev(cmr_index_t* idx, const float* q_f32_dev, int32_t nq, int32_t k,
                              int64_t* out_ids_dev, float* out_scores_dev, float* out_min_dev,
                              float* out_max_dev, void* stream);
@@ -347,14 +352,35 @@ int32_t cmr_pool_l2norm(int32_t device_id, const void* hidden_dev, int32_t hidde
  *   finite values (zeros where a whole 128-row block is padding): the pooling mask drops them.
  * cmr_encoder_embed_layernorm: out[t] = LayerNorm(word[ids[t]] + position[t mod l] + token_type[tt[t]]) for the rows = b*l tokens
  *   of a [b, l] mini-batch (transformers' BertEmbeddings with default position ids; token_type_dev NULL = type 0; ids outside a
- *   table are clamped into it).
+ *   table are clamped into it).  position_offset: 0 for BERT; padding_idx + 1 for the RoBERTa family (XLM-R = bge-m3), whose
+ *   position table starts there (RobertaEmbeddings.create_position_ids_from_input_ids on right-padded rows: token t of a sequence
+ *   sits at position t + padding_idx + 1; the padded tail's embeddings are never used).
  * cmr_encoder_add_layernorm: out = LayerNorm(y + bias + residual) * gamma + beta over rows of d elements, fp32 statistics
  *   (BertSelfOutput / BertOutput after their dense GEMM); bias_dev / residual_dev may be NULL.                              */
+/* The LAST layer's cmr_encoder_add_layernorm with the encoder tail folded in — mean_pooling over the tokens < lens[s]
+ * (embedding_model/BGEEmbedding.py:15-28) and F.normalize (:126-127, eps 1e-12; normalize = 0: the plain masked mean) of the
+ * [b, l, d] mini-batch it would have written: out_dev [b, d] fp32; the hidden state itself is never stored (a 16-token block per
+ * workgroup -> one fp32 partial row, summed in block order by a small second launch; every value is rounded to 16 bits before it
+ * is added, as the stored hidden state would have been).  l % 16 == 0, d % 8 == 0, d <= 2048, 16-byte aligned buffers, right-padded
+ * sequences (lens_dev [b] int32): CMR_ERR_UNSUPPORTED otherwise — callers then run add_layernorm + cmr_pool_l2norm.             */
+int32_t cmr_encoder_add_layernorm_pool(int32_t device_id, const void* y_dev, const void* bias_dev, const void* residual_dev,
+                                       const void* gamma_dev, const void* beta_dev, float eps, int32_t b, int32_t l, int32_t d,
+                                       int32_t dtype, const int32_t* lens_dev, int32_t normalize, float* partial_dev /* scratch:
+                                       b * (l / 16) * d floats, caller-owned so that a stream capture allocates nothing */,
+                                       float* out_dev, void* stream);
 int32_t cmr_encoder_embed_layernorm(int32_t device_id, const int64_t* ids_dev, const int64_t* token_type_dev,
                                     const void* word_dev, const void* pos_dev, const void* type_dev,
                                     const void* gamma_dev, const void* beta_dev, float eps, int64_t rows, int32_t l,
-                                    int32_t d, int32_t vocab, int32_t n_positions, int32_t n_types, int32_t dtype,
-                                    void* out_dev, void* stream);
+                                    int32_t d, int32_t vocab, int32_t n_positions, int32_t n_types, int32_t position_offset,
+                                    int32_t dtype, void* out_dev, void* stream);
+/* cmr_encoder_embed_layernorm from RAGGED token ids: ids32_dev holds the b sequences' tokens back to back (int32), offsets_dev[b + 1]
+ * their starts; row (s, t) of the [b, l] mini-batch embeds token t of sequence s (token 0 behind its end: padding rows, masked
+ * downstream), token type 0.  What the host ships per mini-batch is then ONE int32 array lens | offsets | ids — no padded id, mask
+ * or token-type tensors (the tokenizer call of embedding_model/BGEEmbedding.py:112-118 pads on the host and uploads three).     */
+int32_t cmr_encoder_embed_layernorm_ragged(int32_t device_id, const int32_t* ids32_dev, const int32_t* offsets_dev, const void* word_dev,
+                                           const void* pos_dev, const void* type_dev, const void* gamma_dev, const void* beta_dev, float eps,
+                                           int32_t b, int32_t l, int32_t d, int32_t vocab, int32_t n_positions, int32_t position_offset,
+                                           int32_t dtype, void* out_dev, void* stream);
 int32_t cmr_encoder_attention(int32_t device_id, const void* qkv_dev, int32_t dtype, const int32_t* lens_dev,
                               int32_t b, int32_t l, int32_t n_heads, int32_t head_dim, void* out_dev, void* stream);
 int32_t cmr_encoder_add_layernorm(int32_t device_id, const void* y_dev, const void* bias_dev,

@@ -41,6 +41,31 @@ def tiny_bert(hidden=64, layers=2, heads=4, inter=128, max_pos=128, vocab_words=
     return model, fast
 
 
+def tiny_xlmr(hidden=256, layers=2, heads=4, inter=512, max_pos=2050, seed=0):
+    """A seed-initialised XLM-RoBERTa encoder (bge-m3's architecture: position ids start at padding_idx + 1 = 2, one token type,
+    LayerNorm eps 1e-5) + a synthetic tokenizer whose <pad> has id 1 like XLM-R's (no sentencepiece model exists offline)."""
+    import torch
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast, XLMRobertaConfig, XLMRobertaModel
+    words = ("the a an and of to in she he it her his was were had be good pious mother grave snow spring prince slipper golden ball "
+             "pumpkin coach midnight stepmother sisters bird tree wish dress dance king son generate representation for this sentence "
+             "retrieve relevant articles what who how did when").split()
+    vocab = {t: i for i, t in enumerate(["<s>", "<pad>", "</s>", "<unk>", "<mask>"])}
+    for w in words + [f"##{c}" for c in "abcdefghijklmnopqrstuvwxyz"] + list("abcdefghijklmnopqrstuvwxyz") + list(".,:;?!'\"-"):
+        vocab.setdefault(w, len(vocab))
+    tok = Tokenizer(models.WordPiece(vocab=vocab, unk_token="<unk>"))
+    tok.normalizer = normalizers.BertNormalizer(lowercase=True)
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A </s>", special_tokens=[("<s>", 0), ("</s>", 2)])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, pad_token="<pad>", unk_token="<unk>", cls_token="<s>", sep_token="</s>",
+                                   bos_token="<s>", eos_token="</s>", mask_token="<mask>")
+    torch.manual_seed(seed)
+    cfg = XLMRobertaConfig(vocab_size=len(vocab), hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+                           max_position_embeddings=max_pos, type_vocab_size=1, pad_token_id=1, bos_token_id=0, eos_token_id=2, layer_norm_eps=1e-5)
+    model = XLMRobertaModel(cfg, add_pooling_layer=False).eval()
+    return model, fast
+
+
 def mean_pooling(token_embeddings, mask):
     """BGEEmbedding.py:15-28."""
     token_embeddings = token_embeddings.masked_fill(~mask[..., None].bool(), 0.)

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/comorag_hip.h but not exported"
     assert sorted(L.SIGNATURES) == syms, "ctypes binding table and header drifted"
-    assert lib.cmr_abi_version() == 1
+    assert lib.cmr_abi_version() == 2
 
 
 def test_host_merge_is_pure_host_code():

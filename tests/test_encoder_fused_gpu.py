@@ -20,6 +20,7 @@ class _Stages:
         self.cmr_dtype = L.CMR_BF16 if dtype == torch.bfloat16 else L.CMR_F16
         self.attention = FusedBertLayers.attention.__get__(self)
         self.add_layernorm = FusedBertLayers.add_layernorm.__get__(self)
+        self.add_layernorm_pool = FusedBertLayers.add_layernorm_pool.__get__(self)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
@@ -63,6 +64,35 @@ def test_add_layernorm_kernel(dtype, d, rows, parts):
     z = y.float() + (bias.float() if use_b else 0) + (res.float() if use_r else 0)
     want = torch.nn.functional.layer_norm(z, (d,), gamma.float(), beta.float(), 1e-12)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=TOL[dtype], rtol=TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+@pytest.mark.parametrize("b,l,d", [(5, 64, 768), (32, 512, 768), (3, 128, 1024), (2, 16, 256), (4, 48, 2048), (1, 32, 72)])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_last_layer_layernorm_with_the_encoder_tail_folded_in(dtype, b, l, d, normalize):
+    """cmr_encoder_add_layernorm_pool == cmr_encoder_add_layernorm followed by cmr_pool_l2norm (mean_pooling + F.normalize,
+    BGEEmbedding.py:15-28, :126-127) on the same inputs — ragged right-padded lengths incl. a one-token row, a row that ends
+    inside a 16-token block and a full one — and both against the fp32 formula on the 16-bit-rounded LayerNorm output."""
+    import torch
+    from comorag_amd.embedding_model.bge import pool_l2norm
+    dt = getattr(torch, dtype)
+    g = torch.Generator(device="cuda"); g.manual_seed(b * 1000 + l + d)
+    y = torch.randn((b * l, d), generator=g, device="cuda").to(dt)
+    res = torch.randn((b * l, d), generator=g, device="cuda").to(dt)
+    bias, gamma, beta = (torch.randn(d, generator=g, device="cuda").to(dt) for _ in range(3))
+    lens = torch.tensor(([1, l, max(1, l - 5), max(1, l // 2 + 3), 17] * 8)[:b], dtype=torch.int32).clamp_(max=l)
+    mask = (torch.arange(l)[None, :] < lens[:, None]).to(torch.int64)
+    fz = _Stages(d, 1, dt, eps=1e-12)
+    hidden = fz.add_layernorm(y, bias, res, gamma, beta).view(b, l, d)
+    two = pool_l2norm(hidden, mask.cuda(), normalize=normalize)
+    one = fz.add_layernorm_pool(y, bias, res, gamma, beta, lens.cuda(), b, l, normalize)
+    torch.cuda.synchronize()
+    want = (hidden.float() * mask.cuda()[..., None]).sum(1) / lens.cuda()[:, None].float()
+    if normalize:
+        want = torch.nn.functional.normalize(want, p=2, dim=1)
+    tol = 3e-6 if normalize else 3e-5
+    np.testing.assert_allclose(one.cpu().numpy(), want.cpu().numpy(), atol=tol, rtol=1e-5)
+    np.testing.assert_allclose(one.cpu().numpy(), two.cpu().numpy(), atol=tol, rtol=1e-5)
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
@@ -170,7 +200,7 @@ def test_captured_graphs_equal_eager_forwards_also_from_many_threads():
         for q, w in zip(queries, want):
             np.testing.assert_allclose(em.batch_encode(q), w, atol=2e-6)
     shapes = set(em._fused._graphs)
-    assert 1 <= len(shapes) <= len(queries) and all(l % 16 == 0 for _, l, _ in shapes)
+    assert 1 <= len(shapes) <= len(queries) and all(key[1] % 16 == 0 for key in shapes)
     batch = em.batch_encode(queries)                        # a 6-row mini-batch: another shape, first eager
     for _ in range(3):
         np.testing.assert_allclose(em.batch_encode(queries), batch, atol=2e-6)
@@ -179,3 +209,74 @@ def test_captured_graphs_equal_eager_forwards_also_from_many_threads():
     for i, g in enumerate(got):
         np.testing.assert_allclose(g, want[i % len(queries)], atol=2e-6)
     em.close(); eager.close()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind,dtype", [("base", "bf16"), ("large", "fp16")])
+def test_bge_base_and_large_shapes_ragged_512_tokens_vs_fp32_oracle(kind, dtype):
+    """The shapes BASELINE names — BGE-base (12 x 768, bf16) and BGE-large (24 x 1024, fp16) — through the product path
+    (tokenise -> fused 16-bit layer stack -> HIP pool + L2-norm) on 32 ragged chunks of up to 512 tokens, against the oracle's
+    fp32 restatement of the reference's batch_encode on the same (16-bit-representable) weights: north_star's
+    'cosine scores within 1e-3 for bf16' per row and per pairwise score.  Random-init attention is near-uniform, so the
+    query / key projections are scaled up to make the softmax matter (as in the toy-size test above)."""
+    import torch
+    from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
+    from comorag_amd.utils.config_utils import BaseConfig
+    from tools.bench_extras import encoder_parity
+    from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
+    tok, words = synthetic_wordpiece_tokenizer()
+    model = random_bert(kind, vocab_size=len(tok))
+    with torch.no_grad():
+        for lyr in model.encoder.layer:
+            lyr.attention.self.query.weight.mul_(2.0)          # logit std ~1.5 (x6 saturates the softmax: an arg-max flip per rounding error,
+            lyr.attention.self.key.weight.mul_(2.0)            # the fp32 / 16-bit comparison then measures chaos, not arithmetic)
+    cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_batch_size=8, embedding_model_dtype=dtype)
+    em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=model, tokenizer=tok)
+    assert em.encoder_path == "hip-fused-layers"
+    chunks = synthetic_chunks(words, 32, tokens_per_chunk=560)
+    r = encoder_parity(torch, em, chunks)
+    assert r["min_row_cosine_vs_fp32_oracle"] >= 1.0 - 1e-3, r
+    assert r["max_abs_pairwise_score_diff"] <= 1e-3, r
+    # and no further from fp32 than the reference's own code run in the same 16-bit dtype (transformers forward + torch pooling)
+    assert 1.0 - r["min_row_cosine_vs_fp32_oracle"] <= 2.0 * (1.0 - r["transformers_same_dtype_min_row_cosine"]) + 1e-5, r
+    em.close()
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_xlm_roberta_stack_at_2048_tokens_vs_fp32_oracle(dtype):
+    """bge-m3's architecture (XLM-RoBERTa: position ids from padding_idx + 1, one token type, eps 1e-5) through the fused stack at
+    the reference's default embedding_max_seq_len = 2048 (utils/config_utils.py:140) — the one BGE model that length is safe with
+    (SURVEY.md 5): a row that fills all 2048 positions, ragged ones, a two-token one, against the fp32 oracle (the reference's
+    batch_encode restated, HF's own position ids) on the same 16-bit-representable weights, and the transformers forward."""
+    import torch
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.embedding_model import fused_bert
+    from comorag_amd.utils.config_utils import BaseConfig
+    from oracle import encode_torch as enc
+    model, tok = enc.tiny_xlmr(hidden=256, layers=2, heads=4, inter=512, max_pos=2050)
+    with torch.no_grad():
+        for lyr in model.encoder.layer:
+            lyr.attention.self.query.weight.mul_(10.0)
+            lyr.attention.self.key.weight.mul_(10.0)
+        model.to(getattr(torch, dtype)).float()
+    assert fused_bert.position_offset(model) == 2 and fused_bert.why_not(copy.deepcopy(model).to(torch.bfloat16)) is None
+    texts = ["the prince and the golden slipper and the bird in the tree " * 200, "she was good and pious " * 150, "midnight",
+             "what did the mother wish " * 60, "who how when " * 11]
+    want = enc.batch_encode(model, tok, texts, batch_size=4, max_length=2048)
+    cls = _get_embedding_model_class("bge-m3-random")
+    out = {}
+    for fused in (True, False):
+        cfg = BaseConfig(embedding_model_name="bge-m3-random", embedding_batch_size=4, embedding_model_dtype=dtype, embedding_fused_encoder=fused)
+        assert cfg.embedding_max_seq_len == 2048
+        em = cls(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+        assert em.max_positions == 2048
+        assert em.encoder_path == ("hip-fused-layers" if fused else "transformers")
+        out[fused] = em.batch_encode(texts)
+        em.close()
+    ntok = [len(tok(enc.BGE_PREFIX + t, truncation=True, max_length=2048)["input_ids"]) for t in texts]
+    assert max(ntok) == 2048 and min(ntok) < 40
+    tol = {"bfloat16": 6e-3, "float16": 1e-3}[dtype]
+    np.testing.assert_allclose(out[True], want, atol=tol)
+    np.testing.assert_allclose(out[False], want, atol=tol)
+    assert np.abs(out[True] - want).max() <= 2.0 * np.abs(out[False] - want).max() + 2e-4
+    assert float(np.min((out[True] * want).sum(1))) > 0.9995

@@ -106,7 +106,35 @@ def bert_flops_per_chunk(hidden, layers, tokens, inter_mult=4):
     return 2.0 * tokens * layers * ((4 + 2 * inter_mult) * hidden * hidden + 2.0 * tokens * hidden)
 
 
-def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, batch=32, tok_processes=0):
+def encoder_parity(torch, em, chunks, n=32, peak=None):
+    """The product encode path (`em.batch_encode`: tokenise -> 16-bit layer stack -> HIP pool + L2-norm) against the oracle's fp32
+    restatement of the reference's batch_encode (oracle/encode_torch.py, CPU) on the SAME 16-bit-representable weights, for n
+    RAGGED chunks (17 ... ~512 word pieces).  north_star's bar for 16-bit arithmetic: cosine scores within 1e-3 —
+    reported: the worst row cosine between the two embeddings and the worst difference of any pairwise score."""
+    import copy
+    from oracle import encode_torch as enc_o
+    ragged = [" ".join(c.split()[:17 + (i * 16) % 500]) for i, c in enumerate(chunks[:n])]
+    model32 = copy.deepcopy(em.embedding_model).float().cpu().eval()
+    maxlen = int(getattr(em.embedding_model.config, "max_position_embeddings", 512))
+    want = enc_o.batch_encode(model32, em.tokenizer, ragged, batch_size=8, max_length=maxlen)
+    got = em.batch_encode(ragged)
+    cos = (got.astype(np.float64) * want.astype(np.float64)).sum(1)
+    ds = np.abs(got.astype(np.float64) @ got.astype(np.float64).T - want.astype(np.float64) @ want.astype(np.float64).T)
+    out = {"rows": len(ragged), "min_row_cosine_vs_fp32_oracle": float(cos.min()), "max_abs_pairwise_score_diff": float(ds.max()),
+           "max_abs_component_diff": float(np.abs(got - want).max()), "bar": "|cos - 1| <= 1e-3 and |score diff| <= 1e-3 (north_star, 16-bit)",
+           "parity": bool(cos.min() >= 1.0 - 1e-3 and ds.max() <= 1e-3),
+           "oracle": "oracle/encode_torch.batch_encode (BGEEmbedding.py:92-185 restated), fp32 on the host, same weights"}
+    # the reference's own code in the SAME 16-bit dtype (transformers forward on the GPU + torch pooling): what 16-bit arithmetic
+    # costs without any of this repo's kernels
+    dev = next(em.embedding_model.parameters()).device
+    plain = np.concatenate([enc_o.encode(em.embedding_model, em.tokenizer, ragged[i:i + 8], instruction=enc_o.BGE_PREFIX, max_length=maxlen).float().cpu().numpy()
+                            for i in range(0, len(ragged), 8)]).astype(np.float64)
+    out["transformers_same_dtype_min_row_cosine"] = float((plain * want.astype(np.float64)).sum(1).min())
+    out["transformers_same_dtype_max_abs_pairwise_score_diff"] = float(np.abs(plain @ plain.T - want.astype(np.float64) @ want.astype(np.float64).T).max())
+    return out
+
+
+def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, batch=32, tok_processes=0, parity=True):
     """Corpus-embed chunks/s end to end and where the time goes: tokenizer alone (host), forward + pool alone (device
     inputs ready), pool kernel alone; MFMA fraction of the forward from the model's matmul flops."""
     from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel, pool_l2norm
@@ -178,6 +206,7 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
            "frac_of": ("2.5 PFLOP/s dense bf16/fp16 MFMA" if dtype != "auto" else "157 TFLOP/s fp32") + " for the forward alone (GEMMs: PyTorch-ROCm / hipBLASLt, by north_star's design; attention and bias + residual + LayerNorm: HIP for 16-bit BERT encoders); end-to-end = tokenizer overlapped with forward + HIP pool",
            "end_to_end_over_forward_only": (n_chunks / dt_e2e) / fwd_rate, "tokenizer_processes": tok_processes,
            "encoder_path": em.encoder_path, **stages,
+           **({"parity_vs_fp32_oracle": encoder_parity(torch, em, chunks)} if parity and dtype != "auto" else {}),
            "host_ms": {"end_to_end": dt_e2e * 1e3, "waiting_for_token_ids": sum(t[0] for t in trace) * 1e3,
                        "padding_and_launching": sum(t[1] for t in trace) * 1e3, "windows": len(trace)}}
     return res, em
