@@ -8,18 +8,26 @@ tokenizer from its JSON; what it returns — truncated, unpadded id arrays — h
 from __future__ import annotations
 
 _TOK = None
+_TRUNC = {"strategy": "longest_first", "direction": "right"}
+_LEN = None
 
 
-def init(tokenizer_json: str) -> None:
+def init(tokenizer_json: str, direction: str = "right", strategy: str = "longest_first") -> None:
+    """direction / strategy: the in-process path's truncation settings (bge.py:_backend honours tokenizer.truncation_side) —
+    a left-truncating tokenizer must yield the same ids from a worker process."""
     global _TOK
     from tokenizers import Tokenizer
     _TOK = Tokenizer.from_str(tokenizer_json)
     _TOK.no_padding()
+    _TRUNC["direction"], _TRUNC["strategy"] = direction, strategy
 
 
 def ragged(prompts, max_length: int):
     """Token ids per prompt as int32 arrays (a pickled array crosses the pipe as one buffer; a list of 512 Python ints is
     512 objects to rebuild on the side that also launches the encoder's kernels)."""
     import numpy as np
-    _TOK.enable_truncation(max_length=int(max_length))
+    global _LEN
+    if _LEN != int(max_length):          # configured once per length, not per call
+        _TOK.enable_truncation(int(max_length), stride=0, strategy=_TRUNC["strategy"], direction=_TRUNC["direction"])
+        _LEN = int(max_length)
     return [np.asarray(e.ids, dtype=np.int32) for e in _TOK.encode_batch(list(prompts))]

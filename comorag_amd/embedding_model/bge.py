@@ -141,11 +141,12 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self._bt_copies, self._bt_lock = {}, threading.Lock()
         self._tok_procs = None
         n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", 0) or 0)
-        if n_procs > 0 and hasattr(tokenizer, "backend_tokenizer"):
+        if n_procs > 0 and self._fast_tok:
             import multiprocessing as mp
             from . import _tokworker
             self._tok_procs = mp.get_context("spawn").Pool(min(n_procs, os.cpu_count() or 1), initializer=_tokworker.init,
-                                                           initargs=(tokenizer.backend_tokenizer.to_str(),))
+                                                           initargs=(tokenizer.backend_tokenizer.to_str(), getattr(tokenizer, "truncation_side", "right"),
+                                                                     "longest_first"))
         self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
         if self._cached:
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
@@ -183,10 +184,27 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         return bt
 
     def _ragged(self, prompts: List[str], max_length: int):
-        """Token ids per prompt, truncated, not padded: what `tokenizer(prompts, truncation=True, max_length=...)` yields."""
+        """Token ids per prompt, truncated, not padded: what `tokenizer(prompts, truncation=True, max_length=...)` yields — as int32
+        arrays (made on the tokenizer's thread: the launching thread only ever concatenates them)."""
         if self._fast_tok:
-            return [e.ids for e in self._backend(max_length).encode_batch(list(prompts))]
-        return tokenize_ragged(self.tokenizer, prompts, max_length)
+            return [np.asarray(e.ids, dtype=np.int32) for e in self._backend(max_length).encode_batch(list(prompts))]
+        return [np.asarray(x, dtype=np.int32) for x in tokenize_ragged(self.tokenizer, prompts, max_length)]
+
+    def _forward_ragged(self, id_arrays, normalize: bool):
+        """One mini-batch of the fused stack from ragged id arrays: ONE int32 array lens | offsets | ids goes to the device
+        (fused_bert.FusedBertLayers.forward_ragged); returns the pooled rows [b, D] fp32 on the GPU."""
+        b = len(id_arrays)
+        head = np.empty(2 * b + 1, dtype=np.int32)
+        lens = head[:b]
+        lens[:] = [len(x) for x in id_arrays]
+        head[b] = 0
+        np.cumsum(lens, out=head[b + 1:])
+        width = -(-int(lens.max()) // 16) * 16        # rows are padded (on the device) to the longest one, rounded up to 16 tokens
+        return self._fused.forward_ragged(np.concatenate([head, *id_arrays]), b, width, normalize)
+
+    def _ragged_ok(self) -> bool:
+        """Can mini-batches go to the device as ragged ids (fused stack, right-padding single-segment tokenizer, every row non-empty)?"""
+        return self._fused is not None and getattr(self.tokenizer, "padding_side", "right") == "right" and self._fused.can_pool(16)
 
     def _tokenize(self, prompts: List[str], max_length: int):
         """The tensors of `tokenizer(prompts, padding=True, truncation=True, max_length=..., return_tensors="pt")` (:112-117)."""
@@ -230,6 +248,10 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         if instruction:
             prompts = [instruction + text for text in prompts]
         max_length = kwargs.get("max_length", self.embedding_config.encode_params.get("max_length", 512))
+        if self._ragged_ok():
+            ids = self._ragged(prompts, min(int(max_length), self.max_positions))
+            if all(len(x) for x in ids):
+                return self._forward_ragged(ids, kwargs.get("normalize", True))
         return self._forward_pool(self._tokenize(prompts, max_length), kwargs.get("normalize", True))
 
     # ------------------------------------------------------------------ public
@@ -317,7 +339,10 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                             end += 1
                         groups.append(order[start:end])
                         start = end
-                    parts = [self._forward_pool(pad_batch(self.tokenizer, [id_lists[j] for j in g]), normalize) for g in groups]
+                    if self._ragged_ok() and lens.min() > 0:
+                        parts = [self._forward_ragged([id_lists[j] for j in g], normalize) for g in groups]
+                    else:
+                        parts = [self._forward_pool(pad_batch(self.tokenizer, [id_lists[j] for j in g]), normalize) for g in groups]
                     if results is None:
                         results = torch.empty((len(texts), parts[0].shape[1]), dtype=parts[0].dtype, device=parts[0].device)
                     # (pinned index: a pageable copy would hold the host until this window's forwards have all finished)

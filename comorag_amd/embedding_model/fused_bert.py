@@ -137,6 +137,21 @@ class FusedBertLayers:
                                                     C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
         return out
 
+    def embed_ragged(self, ids32, offsets, b: int, l: int, stream: Optional[int] = None):
+        """BertEmbeddings straight from ragged token ids (int32 CUDA tensors: the b sequences back to back + their b + 1 starts)
+        → [b*l, hidden]; rows behind a sequence's end are padding."""
+        import torch
+        word, pos, typ, gamma, beta = self.emb
+        out = torch.empty((b * l, self.hidden), dtype=word.dtype, device=ids32.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(ids32.device).cuda_stream
+        L.check(L.lib().cmr_encoder_embed_layernorm_ragged(ids32.device.index or 0, C.c_void_p(ids32.data_ptr()), C.c_void_p(offsets.data_ptr()),
+                                                           C.c_void_p(word.data_ptr()), C.c_void_p(pos.data_ptr()), C.c_void_p(typ.data_ptr()),
+                                                           C.c_void_p(gamma.data_ptr()), C.c_void_p(beta.data_ptr()), self.eps, b, l, self.hidden,
+                                                           word.shape[0], pos.shape[0], int(getattr(self, "pos_offset", 0)), self.cmr_dtype,
+                                                           C.c_void_p(out.data_ptr()), C.c_void_p(stream)))
+        return out
+
     def add_layernorm(self, y, bias, residual, gamma, beta, stream: Optional[int] = None):
         import torch
         out = torch.empty_like(y)
@@ -175,7 +190,18 @@ class FusedBertLayers:
         import torch.nn.functional as F
         b, l = input_ids.shape
         stream = torch.cuda.current_stream(input_ids.device).cuda_stream
-        x = self.embed(input_ids, token_type_ids, stream)
+        return self._layers(self.embed(input_ids, token_type_ids, stream), lens_dev, b, l, pool, stream)
+
+    def _stack_ragged(self, packed, b: int, l: int, pool):
+        """The same from ONE int32 tensor lens[b] | offsets[b + 1] | token ids (ragged, back to back)."""
+        import torch
+        stream = torch.cuda.current_stream(packed.device).cuda_stream
+        x = self.embed_ragged(packed[2 * b + 1:], packed[b:2 * b + 1], b, l, stream)
+        return self._layers(x, packed[:b], b, l, pool, stream)
+
+    def _layers(self, x, lens_dev, b: int, l: int, pool, stream):
+        import torch
+        import torch.nn.functional as F
         last = len(self.layers) - 1
         for n, (wqkv, bqkv, wo, bo, g1, be1, w1, b1, w2, b2, g2, be2) in enumerate(self.layers):
             qkv = F.linear(x, wqkv, bqkv)
@@ -218,13 +244,14 @@ class FusedBertLayers:
                         if len(self._seen) > 4096:               # a corpus of ragged shapes: forget the counts, keep the graphs
                             self._seen.clear()
                         seen = self._seen[key] = self._seen.get(key, 0) + 1
-                        if seen >= 2 and len(self._graphs) < self.graphs:
+                        if seen >= 2 and self._room_for_a_graph():
                             ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None, pool)
                     if ent is not None:
                         cur = torch.cuda.current_stream(input_ids.device)
                         if ent.get("stream") is not None and ent["stream"] != cur:
                             cur.wait_stream(ent["stream"])          # a caller on another stream: order behind the last reader of the buffers
                         ent["stream"] = cur
+                        self._touch(ent)
                         ent["ids"].copy_(input_ids, non_blocking=True)
                         ent["lens"].copy_(lens_src, non_blocking=True)
                         if token_type_ids is not None:
@@ -235,6 +262,75 @@ class FusedBertLayers:
                         return consume(ent["hidden"]) if consume is not None else ent["hidden"].clone()
             hidden = self._stack(input_ids, lens_src.to(input_ids.device, non_blocking=True), token_type_ids, pool)
             return hidden if pool is not None else (consume(hidden) if consume is not None else hidden)
+
+    def forward_ragged(self, packed_host: np.ndarray, b: int, l: int, normalize: bool = True):
+        """One mini-batch from the tokenizer's ragged output: packed_host = int32 [lens (b) | offsets (b + 1) | token ids back to
+        back], l = the padded width (a multiple of 16, >= the longest sequence).  Returns the pooled rows [b, hidden] fp32
+        (masked mean, L2-normalised unless normalize = False).  The host ships ONE pinned array per mini-batch — no padded id /
+        mask / token-type tensors are built on either side of the link; a shape seen before replays its captured hipGraph."""
+        import torch
+        if l % 16 or not self.can_pool(l):
+            raise ValueError("forward_ragged needs a padded width that is a multiple of 16")
+        n = int(packed_host.shape[0])
+        with torch.no_grad():
+            src = torch.from_numpy(packed_host).pin_memory()        # pinned: a pageable source makes the host wait for the stream
+            key = (b, l, "ragged", bool(normalize))
+            if self.graphs > 0:
+                with self._glock:
+                    ent = self._graphs.get(key)
+                    if ent is None:
+                        if len(self._seen) > 4096:
+                            self._seen.clear()
+                        seen = self._seen[key] = self._seen.get(key, 0) + 1
+                        if seen >= 2 and self._room_for_a_graph():
+                            ent = self._graphs[key] = self._capture_ragged(b, l, bool(normalize))
+                    if ent is not None:
+                        cur = torch.cuda.current_stream(self.device)
+                        if ent.get("stream") is not None and ent["stream"] != cur:
+                            cur.wait_stream(ent["stream"])
+                        ent["stream"] = cur
+                        self._touch(ent)
+                        ent["packed"][:n].copy_(src, non_blocking=True)
+                        ent["graph"].replay()
+                        return ent["hidden"].clone()
+            return self._stack_ragged(src.to(self.device, non_blocking=True), b, l, bool(normalize))
+
+    def _capture_ragged(self, b: int, l: int, normalize: bool):
+        import torch
+        dev = self.device
+        packed = torch.zeros((2 * b + 1 + b * l,), dtype=torch.int32, device=dev)
+        packed[:b] = 1                                              # one token per sequence: a valid batch for the warm-up pass
+        packed[b:2 * b + 1] = torch.arange(b + 1, dtype=torch.int32, device=dev)
+        ent = {"packed": packed}
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self._stack_ragged(packed, b, l, normalize)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            ent["hidden"] = self._stack_ragged(packed, b, l, normalize)
+        ent["graph"] = graph
+        return ent
+
+    def _room_for_a_graph(self) -> bool:
+        """Called under the lock before a capture: with the table full, the graph that was replayed longest ago goes (its static
+        buffers and private pool return to PyTorch's allocator once nothing references them) — the first `graphs` shapes of a
+        process must not occupy the table forever while the shapes of today's corpus run eagerly."""
+        if self.graphs <= 0:
+            return False
+        if len(self._graphs) >= self.graphs:
+            victim = min(self._graphs, key=lambda k: self._graphs[k].get("used", 0))
+            st = self._graphs[victim].get("stream")
+            if st is not None:
+                st.synchronize()              # its last replay (and the reader of its output) are done
+            del self._graphs[victim]
+        return True
+
+    def _touch(self, ent) -> None:
+        self._clock = getattr(self, "_clock", 0) + 1
+        ent["used"] = self._clock
 
     def _capture(self, b: int, l: int, has_tt: bool, pool=None):
         """Static buffers + one eager pass on a side stream (allocator and GEMM-heuristic warm-up) + the captured pass."""

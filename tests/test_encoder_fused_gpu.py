@@ -280,3 +280,42 @@ def test_xlm_roberta_stack_at_2048_tokens_vs_fp32_oracle(dtype):
     np.testing.assert_allclose(out[False], want, atol=tol)
     assert np.abs(out[True] - want).max() <= 2.0 * np.abs(out[False] - want).max() + 2e-4
     assert float(np.min((out[True] * want).sum(1))) > 0.9995
+
+
+@pytest.mark.parametrize("kind", ["bert", "xlmr"])
+def test_ragged_mini_batches_equal_padded_ones(kind):
+    """The host ships ONE int32 array lens | offsets | ids per mini-batch (FusedBertLayers.forward_ragged, embed_ln_ragged_kernel)
+    instead of the padded id / mask / token-type tensors of BGEEmbedding.py:112-118: same embeddings rows for the real tokens,
+    same pooled output as the padded call, eager and as a captured graph."""
+    import torch
+    from comorag_amd.embedding_model.fused_bert import FusedBertLayers
+    from oracle import encode_torch as enc
+    model, tok = (enc.tiny_bert(hidden=256, layers=2, heads=4, inter=512, max_pos=160) if kind == "bert"
+                  else enc.tiny_xlmr(hidden=256, layers=2, heads=4, inter=512, max_pos=162))
+    fz = FusedBertLayers(model.to("cuda", dtype=torch.bfloat16), graphs=4)
+    rng = np.random.default_rng(7)
+    lens = np.array([1, 160, 33, 16, 97, 2], np.int32)
+    ids = [rng.integers(5, len(tok), n).astype(np.int32) for n in lens]
+    b, l = len(lens), 160
+    padded = np.full((b, l), tok.pad_token_id, np.int64)
+    for r, x in enumerate(ids):
+        padded[r, :len(x)] = x
+    head = np.concatenate([lens, np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)])
+    packed = np.concatenate([head, *ids]).astype(np.int32)
+    pd = torch.from_numpy(packed).cuda()
+    a = fz.embed(torch.from_numpy(padded).cuda(), None).view(b, l, -1)
+    r = fz.embed_ragged(pd[2 * b + 1:], pd[b:2 * b + 1], b, l).view(b, l, -1)
+    for i, n in enumerate(lens):
+        assert torch.equal(a[i, :n], r[i, :n])
+    want = fz(torch.from_numpy(padded).cuda(), lens, pool=True).cpu().numpy()
+    for rep in range(3):                                           # eager, capture, replay
+        got = fz.forward_ragged(packed, b, l, True).cpu().numpy()
+        np.testing.assert_array_equal(got, want)
+    assert any(k[2] == "ragged" for k in fz._graphs)
+    # more shapes than the table holds: the least recently replayed graph goes, the newest shape is captured
+    for width in (16, 32, 48, 64, 80):
+        short = np.concatenate([[3, 5], [0, 3, 8], rng.integers(5, len(tok), 8)]).astype(np.int32)
+        for rep in range(3):
+            fz.forward_ragged(short, 2, width, True)
+    assert len(fz._graphs) == 4 and (2, 80, "ragged", True) in fz._graphs and (2, 16, "ragged", True) not in fz._graphs
+    fz.release()

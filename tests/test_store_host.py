@@ -273,7 +273,8 @@ def test_private_backend_copies_equal_the_tokenizer_call_under_concurrency():
 
     def one(ml):
         rag, pad = em._ragged(texts, ml), em._tokenize(texts, ml)
-        return rag == want[ml][0] and set(pad) == set(want[ml][1]) and all(
+        assert all(a.dtype == np.int32 for a in rag)                        # arrays, made on the tokenizer's thread
+        return [a.tolist() for a in rag] == want[ml][0] and set(pad) == set(want[ml][1]) and all(
             pad[k].dtype == want[ml][1][k].dtype and (pad[k].numpy() == want[ml][1][k].numpy()).all() for k in pad)
     with ThreadPoolExecutor(6) as ex:
         assert all(ex.map(one, [512, 64, 7] * 8))
@@ -292,7 +293,9 @@ def test_fused_encoder_gate_and_mask_lengths():
     assert fused_bert.why_not(m64.to(torch.bfloat16)) is None and fused_bert.why_not(m64.to(torch.float16)) is None
     m64.config.hidden_act = "relu"
     assert "activation" in fused_bert.why_not(m64)
-    assert fused_bert.why_not(object()) == "not a BERT encoder"
+    assert fused_bert.why_not(object()) == "not a BERT / RoBERTa / XLM-R encoder"
+    mx, _ = enc.tiny_xlmr(hidden=128, layers=1, heads=2, inter=128, max_pos=66)
+    assert fused_bert.why_not(mx.to(torch.bfloat16)) is None and fused_bert.position_offset(mx) == 2 and fused_bert.position_offset(m64) == 0
     assert fused_bert.lens_of_mask(np.array([[1, 1, 0, 0], [1, 1, 1, 1]])).tolist() == [2, 4]
     for bad in ([[0, 1, 1]], [[1, 0, 1]], [[0, 0, 0]], [[1, 2, 0]], [1, 1, 0]):
         assert fused_bert.lens_of_mask(np.array(bad)) is None
