@@ -310,8 +310,11 @@ static int ensure_seeds(PprScratch* sc, long long n) {
     return CMR_OK;
 }
 
-// Duplicate seed vertices are summed on the host, in input order (numpy's `w[v] += x` in a loop, ComoRAG.py:1019-1021):
-// the seed kernel then adds every vertex once — no lost update, no atomics, one fixed summation order.
+// Duplicate seed vertices are SUMMED on the host, in input order: the seed kernel then adds every vertex once — no lost update,
+// no atomics, one fixed summation order.  (This is the sparse API's own rule.  The reference's loop ASSIGNS:
+// `phrase_weights[phrase_id] = fact_score` (ComoRAG.py:1019-1021, the last fact that names a phrase wins, then `/= num_chunk`);
+// comorag_amd/hooks.py resolves that on the host and passes distinct vertices, so the rule here never meets a duplicate there.
+// A caller of the sparse C-ABI who wants last-wins must resolve duplicates before the call.)
 static void merge_seeds(const int32_t* v, const double* w, int n, std::vector<int>& ov, std::vector<double>& ow) {
     std::vector<std::pair<int, int>> order((size_t)n);
     for (int i = 0; i < n; ++i) order[i] = {v[i], i};

@@ -113,6 +113,10 @@ class ShardedIndex:
         """Collective append of `rows` [m, dim] (numpy; every rank passes the same rows, only the owner of a chunk uploads
         it).  The rows get the global ids total .. total + m - 1 in order, exactly as one index would number them; returns
         those ids.  Blocks of `block_rows` rows go round robin to the shortest shard (`_route`)."""
+        if not self._owns_local:
+            # a view shares the shard and its block list but keeps its own copy of the running totals: appending through it would
+            # leave the owner (and every other view) with a stale layout, and the ranks would route the next append differently
+            raise RuntimeError("ShardedIndex.view() handles are read-only: append through the handle that owns the shard")
         rows = np.ascontiguousarray(rows, dtype=np.float32)
         if rows.ndim == 1:
             rows = rows[None, :]
@@ -292,8 +296,9 @@ class ShardedIndex:
         return {"world": w.value, "rank": r.value, "rccl_ranks_seen": n.value}
 
     def view(self, exchange: str, timing: bool = False) -> "ShardedIndex":
-        """A second handle on the SAME local shard with the other exchange binding (bench.py gives both bindings hardware
-        time: B = 64 through one, B = 256 through the other).  Closing the view leaves the shard alone."""
+        """A second, READ-ONLY handle on the SAME local shard with the other exchange binding (bench.py gives both bindings
+        hardware time: B = 64 through one, B = 256 through the other): searches only — `append` raises; take the view after the
+        appends (it copies the layout totals of that moment).  Closing the view leaves the shard alone."""
         v = ShardedIndex(self.dim, self.dtype, device=self.device, rank=self.rank, world=self.world, group=self.group, base=self.base,
                          index=_Borrowed(self.local), force_exchange=self.exchange and self.world == 1, exchange=exchange, timing=timing)
         v.local = self.local

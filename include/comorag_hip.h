@@ -230,7 +230,8 @@ int32_t cmr_merge_topk_dev(int32_t device_id, const int64_t* ids_dev, const floa
  *   cmr_graph_set_passage_vertices   vertex of every passage ROW of the index (ComoRAG's passage_node_idxs)
  *   cmr_graph_ppr              run_ppr alone: reset [n_vertices] (negative / NaN -> 0, ComoRAG.py:1090) -> all scores
  *   cmr_index_ppr              the fused path for one query: scan -> min_max_normalize(scores) * passage_node_weight
- *                              scattered into the reset vector on the device, + the (few) phrase seeds -> PPR ->
+ *                              scattered into the reset vector on the device, + the (few) phrase seeds (duplicate seed
+ *                              vertices are SUMMED; ComoRAG's own loop assigns, last wins, :1019-1021 — resolve before the call) -> PPR ->
  *                              out_doc_scores [n_rows] = pagerank[vertex of row]; 8 * n_rows bytes come back instead of
  *                              the 12 * N of the full ranking.  The caller sorts (np.argsort(doc_scores)[::-1], :1102).
  * Power iteration in fp64, ceil(log(tol/2)/log(damping)) steps (<= max_iter; *iters = steps taken), fixed summation

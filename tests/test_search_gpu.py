@@ -179,6 +179,45 @@ def test_wide_batch_register_resident_queries(dtype, d, nq):
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
 
 
+@pytest.mark.parametrize("dtype,d,nq", [("bf16", 384, 256), ("f32", 768, 128), ("f32", 200, 97), ("bf16", 512, 65), ("f16", 1536, 200), ("bf16", 768, 256),
+                                         ("bf16", 1024, 256), ("f16", 768, 193)])
+def test_query_split_grid_of_the_narrow_kernel(dtype, d, nq):
+    """Batches of more than one narrow pass on shapes WITHOUT a register-resident wide kernel (any dim, fp32 indexes) run on the
+    query-split grid of the narrow kernel by default: up to four query tiles walk the same panel ranges in ONE corpus pass.
+    Bit for bit against the narrow passes (scan_no_wide = 1), and against the oracle; for the shapes that do have a wide kernel
+    (768-d / 1024-d, 16-bit) the grid is forced with wide_mode = 2 and held against the wide kernel as well."""
+    X, Q = _mk(40_000 + 17, d, nq, seed=d + nq + 1)
+    X[30_000] = X[11]; Q[3] = X[11]
+    a_ids, a_sc = _check(dtype, X, Q, 20, env={"CMR_WIDE_MODE": "2"})
+    b_ids, b_sc = _check(dtype, X, Q, 20, env={"CMR_SCAN_NO_WIDE": "1"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+    c_ids, c_sc = _check(dtype, X, Q, 20)                        # the default route of this shape
+    assert np.array_equal(a_ids, c_ids) and np.array_equal(a_sc, c_sc)
+    d_ids, d_sc = _check(dtype, X, Q, 100, env={"CMR_WIDE_MODE": "2", "CMR_STREAM_NT": "1"})      # k > 32: 256-entry lists; non-temporal loads
+    e_ids, e_sc = _check(dtype, X, Q, 100, env={"CMR_SCAN_NO_WIDE": "1"})
+    assert np.array_equal(d_ids, e_ids) and np.array_equal(d_sc, e_sc)
+
+
+def test_query_split_grid_sampling_levels_and_pipelined_mode():
+    """300 K rows: both sampling levels run per query group; the pipelined entry point with the grid forced equals the
+    synchronous wide kernel."""
+    import torch
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(300_000, 768, 256, seed=6)
+    a_ids, a_sc = _check("bf16", X, Q, 20, env={"CMR_WIDE_MODE": "2"})
+    idx = DenseIndex(768, "bf16", options={"wide_mode": 2}); idx.append(X)
+    qd = torch.from_numpy(Q).cuda()
+    outs = [(torch.empty((256, 20), dtype=torch.int64, device="cuda"), torch.empty((256, 20), dtype=torch.float32, device="cuda")) for _ in range(2)]
+    for i in range(4):
+        h = idx.search_pipelined(qd, 20, outs[i & 1][0], outs[i & 1][1])
+    idx.sync(h); torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(o[0].cpu().numpy(), a_ids) and np.array_equal(o[1].cpu().numpy(), a_sc)
+    idx.close()
+    b_ids, b_sc = _check("bf16", X, Q, 20, env={"CMR_WIDE_MODE": "1"})
+    assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+
+
 @pytest.mark.parametrize("env", [{}, {"CMR_SCAN_NO_SAMPLE": "1"}])
 @pytest.mark.parametrize("n", [60_000, 9_000])
 def test_wide_batch_ascending_scores_force_compaction(n, env):

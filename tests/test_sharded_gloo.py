@@ -143,3 +143,29 @@ def test_shard_bounds_cover_rows_exactly():
             spans = [shard_bounds(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def test_views_are_read_only():
+    """ShardedIndex.view() shares the shard but copies the layout totals: an append through it would leave the owning handle's
+    routing state stale — it raises instead."""
+    import pytest
+    from comorag_amd.sharded import ShardedIndex
+
+    class _Local:
+        def __init__(self): self.rows = np.empty((0, 4), np.float32)
+        def __len__(self): return len(self.rows)
+        def append(self, r): self.rows = np.concatenate([self.rows, r])
+        def set_id_base(self, b): pass
+        def set_id_blocks(self, l, g): pass
+        def close(self): pass
+
+    sh = ShardedIndex(4, "f32", rank=0, world=1, index=_Local())
+    sh.append(np.ones((3, 4), np.float32))
+    v = sh.view("torch")
+    with pytest.raises(RuntimeError, match="read-only"):
+        v.append(np.ones((2, 4), np.float32))
+    assert len(sh) == 3 and sh.total == 3
+    sh.append(np.ones((2, 4), np.float32))
+    assert sh.total == 5
+    v.close()
+    assert len(sh.local) == 5

@@ -1,16 +1,17 @@
 #!/bin/bash
-# Profile collection on the GPU box (gpurun; ROUND=r3 by default names the outputs): kernel trace of bench.py, PMC traffic passes of the headline
+# Profile collection on the GPU box (gpurun; ROUND=r4 by default names the outputs; bench.py runs with --no-pmc here: its own
+# rocprofv3 passes must not nest inside these): kernel trace of bench.py, PMC traffic passes of the headline
 # configuration, SQ counters + traffic of the wide kernel.  Everything lands in gpurun_out/<round>_profiles/: the summaries AND a
 # compressed per-dispatch CSV of every database (tools/rocpd_dump.py), which is what gets copied into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r3}
+ROUND=${ROUND:-r4}
 O=$R/gpurun_out/${ROUND}_profiles; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $O/kt -o w -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_trace.json 2> $O/kt.err
+rocprofv3 --kernel-trace -d $O/kt -o w -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $O/bench_under_trace.json 2> $O/kt.err
 python $R/tools/rocpd_stats.py $O/kt/w_results.db > $O/${ROUND}_bench_kernel_stats.txt
 python $R/tools/rocpd_dump.py $O/kt/w_results.db $O/${ROUND}_raw_bench_kernel_trace.csv.gz
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o w -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > /dev/null 2> $O/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace -d $O/pmc_$c -o w -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-pmc > /dev/null 2> $O/pmc_$c.err
   python $R/tools/rocpd_pmc.py $O/pmc_$c/w_results.db scan_kernel 1000 > $O/pmc_$c.jsonl
   python $R/tools/rocpd_dump.py $O/pmc_$c/w_results.db $O/${ROUND}_raw_pmc_$c.csv.gz
 done

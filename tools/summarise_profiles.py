@@ -3,7 +3,7 @@ tools/rocpd_pmc.py) into the two PMC files under profiles/:
     python tools/summarise_profiles.py gpurun_out/r2_profiles  ->  <dir>/r2_pmc_hbm_traffic.json, <dir>/r2_pmc_wide.json
 HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count kilobytes; gfx950 tallies 128-B fetch requests at 64 B, hence FETCH x 2."""
 import json, os, sys
-ROUND = os.environ.get("ROUND", "r2")
+ROUND = os.environ.get("ROUND", "r4")
 
 d = sys.argv[1]
 
@@ -31,8 +31,8 @@ if f and w:
                    "WRITE_SIZE": {"launches": w["launches"], "avg_KB": w["avg"], "min_KB": w["min"], "max_KB": w["max"], "avg_kernel_us": w["avg_kernel_us"]}},
            "fetch_bytes_corrected_x2": fetch, "write_bytes": write, "traffic_bytes_per_launch": fetch + write,
            "algorithmic_bytes_per_launch": float(alg), "traffic_over_algorithmic": (fetch + write) / alg,
-           "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra",
-                        "rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"],
+           "commands": ["rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-pmc",
+                        "rocprofv3 --pmc WRITE_SIZE --kernel-trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-pmc"],
            "collected_with": "tools/collect_profiles.sh", "summarised_with": "tools/rocpd_pmc.py + tools/summarise_profiles.py",
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B). Counters are per dispatch: the next "
                    "batch's sampling kernels overlap the main pass but are separate dispatches."}
