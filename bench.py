@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--index-option", action="append", default=[], metavar="NAME=VALUE",
                     help="route selector passed to cmr_index_set_option on this rank's index (A/B runs; DESIGN.md appendix)")
     ap.add_argument("--only-config3", action="store_true", help="after the headline, run the batch-256 row and skip the other extras")
+    ap.add_argument("--survey-rng", action="store_true", help="draw the corpus with numpy default_rng([1234, block]) on the host, literally as SURVEY 8(d) words it (slow: minutes at 10 M rows); default: the same distribution from the device generator")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not re-run a few steps under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic")
     ap.add_argument("--single-process", action="store_true", help="ONE process drives all --gpus devices through MultiDeviceIndex (what hooks.install builds for num_shards = N); no launcher, no collective")
     ap.add_argument("--no-single-process-leg", action="store_true", help="N > 1 under a launcher: skip the single-process leg rank 0 runs afterwards")
@@ -75,17 +76,51 @@ def parse():
     return ap.parse_args()
 
 
+RNG_BLOCK = 1_000_000        # "for N = 10 M generate in 1 M-row blocks with default_rng([1234, blk])"
+SURVEY_RNG = False           # --survey-rng: draw the corpus with numpy on the host exactly as SURVEY 8(d) words it (minutes at 10 M rows)
+
+
+def _host_block(blk, n_rows, dim):
+    """Rows [0, n_rows) of block `blk` of the SURVEY 8(d) corpus: rng = default_rng([1234, blk]); X = rng.standard_normal((1 M, D),
+    float32), row-L2-normalised in fp32 (a prefix of the block's rows is the prefix of its stream: nothing beyond n_rows is drawn)."""
+    x = np.random.default_rng([1234, int(blk)]).standard_normal((int(n_rows), int(dim)), dtype=np.float32)
+    x /= np.sqrt(np.einsum("ij,ij->i", x, x, dtype=np.float32))[:, None]
+    return x
+
+
 def gen_rows_dev(torch, lo, hi, dim, device, block=250_000):
-    """Seeded standard-normal rows, L2-normalised in fp32, generated per 250k-row block from
-    seed (1234, block) so any sharding sees the same global corpus."""
-    b0 = lo // block
-    for b in range(b0, (hi + block - 1) // block):
-        g = torch.Generator(device=device)
-        g.manual_seed(1234 * 1_000_003 + b)
-        x = torch.randn((block, dim), generator=g, device=device, dtype=torch.float32)
-        x = x / x.norm(dim=1, keepdim=True)
-        s, e = max(lo, b * block), min(hi, (b + 1) * block)
-        yield x[s - b * block:e - b * block].contiguous()
+    """Rows [lo, hi) of the synthetic corpus as CUDA tensors of <= `block` rows: seeded standard-normal rows, L2-normalised in
+    fp32, any sharding sees the same global corpus.  Default: drawn ON THE DEVICE per 250 K-row block from seed (1234, block) —
+    the same distribution as SURVEY.md 8(d)'s numpy recipe at a hundredth of its time (numpy draws 65 M samples/s per host thread:
+    two minutes of CPU for 10 M x 768, again for every child run); `--survey-rng` draws with numpy `default_rng([1234, blk])`
+    per 1 M-row block on host threads instead, literally as 8(d) words it."""
+    if not SURVEY_RNG:
+        b0 = lo // block
+        for b in range(b0, (hi + block - 1) // block):
+            g = torch.Generator(device=device)
+            g.manual_seed(1234 * 1_000_003 + b)
+            x = torch.randn((block, dim), generator=g, device=device, dtype=torch.float32)
+            x = x / x.norm(dim=1, keepdim=True)
+            s, e = max(lo, b * block), min(hi, (b + 1) * block)
+            yield x[s - b * block:e - b * block].contiguous()
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    if hi <= lo:
+        return
+    blks = list(range(lo // RNG_BLOCK, (hi - 1) // RNG_BLOCK + 1))
+    need = {b: min(hi, (b + 1) * RNG_BLOCK) - b * RNG_BLOCK for b in blks}      # rows of block b to draw (from its start)
+    workers = max(1, min(len(blks), 4, (os.cpu_count() or 2) // 2))
+    with ThreadPoolExecutor(workers) as ex:
+        futs = {b: ex.submit(_host_block, b, need[b], dim) for b in blks[:workers + 1]}
+        for i, b in enumerate(blks):
+            x = futs.pop(b).result()
+            nxt = i + workers + 1
+            if nxt < len(blks):
+                futs[blks[nxt]] = ex.submit(_host_block, blks[nxt], need[blks[nxt]], dim)
+            s0 = max(lo, b * RNG_BLOCK) - b * RNG_BLOCK
+            for r0 in range(s0, need[b], block):
+                yield torch.from_numpy(x[r0:min(r0 + block, need[b])]).to(device)
+            del x
 
 
 def build_shard(torch, args, rows, rank, world, device, host=None, timing=False):
@@ -108,14 +143,20 @@ def build_shard(torch, args, rows, rank, world, device, host=None, timing=False)
 
 
 def make_queries(torch, n_batches, batch, dim, device, seed):
-    """n_batches distinct batches of unit queries: the timed steps rotate through them, so the data-dependent part of a
-    step (sampling thresholds, slow-path frequency) is not one sample."""
+    """n_batches distinct batches of unit queries (standard-normal, normalised; 10 % of them planted near a
+    corpus row, q = normalise(X[j] + 0.1 g) with X[j] among the corpus' first 4096 rows): the timed steps rotate through them,
+    so the data-dependent part of a step (sampling thresholds, slow-path frequency) is not one sample.  Every rank draws the same
+    batches."""
     out = []
+    n_plant = max(1, batch // 10)
+    x0 = next(iter(gen_rows_dev(torch, 0, 4096, dim, device))).cpu().numpy()      # the corpus' first rows, whichever generator draws it
     for j in range(n_batches):
-        g = torch.Generator(device=device)
-        g.manual_seed(seed + 7919 * j)
-        q = torch.randn((batch, dim), generator=g, device=device, dtype=torch.float32)
-        out.append((q / q.norm(dim=1, keepdim=True)).contiguous())
+        rng = np.random.default_rng([1234, int(seed), j])
+        q = rng.standard_normal((batch, dim), dtype=np.float32)
+        rows = rng.integers(0, len(x0), n_plant)
+        q[:n_plant] = x0[rows] + 0.1 * q[:n_plant] / np.sqrt(dim)       # g scaled to the rows' element size: a near neighbour, not the row itself
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        out.append(torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).to(device))
     torch.cuda.synchronize(device)
     return out
 
@@ -395,7 +436,7 @@ def single_process_main(args):
 
     head, qs, last = run(args.batch, args.steps, args.warmup, 4321)
     out = {"metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (numpy default_rng([1234, block]) rows, SURVEY 8d)" if SURVEY_RNG else ""),
            "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} (north_star target config; corpus fixed, "
                                   f"row-sharded over {n} device(s) driven from ONE process)",
                       "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "process_model": f"one process, {n} shard(s) on devices {devices} (MultiDeviceIndex)",
@@ -438,6 +479,8 @@ def single_process_leg(args):
         cmd.append("--share-device")
     if args.no_extra:
         cmd.append("--no-extra")
+    if args.survey_rng:
+        cmd.append("--survey-rng")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE",
                                                              "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
     t0 = time.perf_counter()
@@ -484,7 +527,9 @@ def self_launch(args):
 
 
 def main():
+    global SURVEY_RNG
     args = parse()
+    SURVEY_RNG = bool(args.survey_rng)
     if args.single_process:
         return single_process_main(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -542,7 +587,7 @@ def main():
     out = {
         "metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (numpy default_rng([1234, block]) rows, SURVEY 8d)" if SURVEY_RNG else ""),
         "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} "
                                f"(north_star target config; corpus fixed, row-sharded over {world} GPU(s))",
                    "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "query_batches_rotated": len(qs),
@@ -608,7 +653,7 @@ def main():
             from tools import pmc_traffic
             torch.cuda.empty_cache()
             argv = ["--rows", str(args.rows), "--dim", str(args.dim), "--batch", str(args.batch), "--k", str(args.k), "--dtype", args.dtype,
-                    "--query-batches", str(args.query_batches)] + [x for o in args.index_option for x in ("--index-option", o)]
+                    "--query-batches", str(args.query_batches)] + [x for o in args.index_option for x in ("--index-option", o)] + (["--survey-rng"] if args.survey_rng else [])
             tr = pmc_traffic.measure(argv)
         except Exception as e:      # noqa: BLE001
             tr = {"error": repr(e)[:300]}

@@ -27,6 +27,8 @@ for b in range(0, rows, 250_000):
 torch.cuda.synchronize()
 routes = [("wide_kernel", {"wide_mode": 1}), ("quad_default_policy", {"wide_mode": 2, "stream_nt": -1}),
           ("quad_nt", {"wide_mode": 2, "stream_nt": 1}), ("narrow_passes", {"scan_no_wide": 1})]
+if os.environ.get("QUAD_AB_ROUTES"):
+    routes = [r for r in routes if r[0] in os.environ["QUAD_AB_ROUTES"].split(",")]
 for B in batches:
     q = torch.randn((B, dim), generator=g, device=dev)
     q = (q / q.norm(dim=1, keepdim=True)).contiguous()
