@@ -158,6 +158,7 @@ struct cmr_index {
     int no_sample = 0;       // scan_no_sample = 1 disables the sampling pass
     int no_wide = 0;         // scan_no_wide = 1 disables the wide-batch (register-resident query) kernel
     int no_tiny = 0;         // scan_no_tiny = 1 disables the single-launch paths (search and all-scores) altogether
+    long long single_level_max = 320000;   // sample_single_max: ONE sampling level while queries x panels stays at or below this
     int single_level = 1;    // sample_single = 0: small batches on mid-size corpora sample in two levels like everything else
     int tiny_multi = 1;      // tiny_multi = 0: the single-launch path always runs as one workgroup (<= 1024 rows only)
     int small_max_panels = 6144;   // small_max_panels: largest corpus (in 32-row panels) the single-launch path takes
@@ -210,6 +211,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "tiny_multi") idx->tiny_multi = (int)v;
     else if (n == "zero_copy") idx->zero_copy = (int)v;
     else if (n == "sample_single") idx->single_level = (int)v;
+    else if (n == "sample_single_max") idx->single_level_max = std::max<long long>(0, v);
     else if (n == "sample_tau_in_scan") idx->tau_in_scan = (int)v;
     else if (n == "sample_div") idx->sample_div = (int)std::max<long long>(2, v);
     else if (n == "sample_maxmul") idx->sample_maxmul = (int)std::max<long long>(0, v);
@@ -231,7 +233,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 // development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
-                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_tau_in_scan", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "sample_div", "sample_maxmul", "pipe_reserve_cus",
                                   "pipe_slots", "wide_waves", "wide_mode", "stream_nt", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
@@ -453,7 +455,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         // around a short scan: ONE sampling level of 128 panels instead of two saves a scan + merge pair (~45 us of a
         // 0.4 ms call at 1 M rows).  Its threshold lets ~k * npanels / 128 scores per query through — a few slow-path
         // entries per wave as long as queries x panels stays small.
-        single_level = !wide && idx->single_level && k <= 32 && nqp <= 8 && npanels >= 4096 && (long long)nqp * npanels <= 320000;
+        single_level = !wide && idx->single_level && k <= 32 && nqp <= 8 && npanels >= 4096 && (long long)nqp * npanels <= idx->single_level_max;
         level_panels[n_levels++] = single_level ? 128 : s0;
         if (npanels >= 4096 && !single_level) {
             // wide kernel: 256 queries share a workgroup, so ANY of 8 tiles beating its threshold stalls all four waves at
@@ -620,6 +622,15 @@ bool wide_pass_is_quad(const cmr_index* idx) {
     if (idx->wide_mode == 1) return false;
     return cmr_wide_queries(idx->dtype, idx->dpad) == 0;
 }
+// A pass of 65 .. 128 queries over a SHORT scan (< 1 ms at the streaming rate: shards up to ~4 M x 768 bf16 rows) runs on the
+// query-split grid although the shape has a wide kernel: two query tiles per corpus block are within what an XCD's L2 hands on
+// (0.39 vs 0.47 ms at 1.25 M rows, B = 128; at 10 M rows the wide kernel wins, 3.26 vs 3.47 — profiles/r4_wide_routes_ab.txt)
+bool short_two_tile_pass(const cmr_index* idx, int left) {
+    if (idx->wide_mode != 0 || idx->no_wide || cmr_wide_queries(idx->dtype, idx->dpad) == 0) return false;
+    if (cmr_scan_max_nqt(idx->dtype, idx->dpad) < 2 || left <= 64 || left > 128) return false;
+    const double scan_us = (double)((idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS) * idx->panel_bytes() / 6.0e6;
+    return scan_us < 1000.0;
+}
 int wide_pass_queries(const cmr_index* idx) {
     if (idx->no_wide) return 0;
     if (!wide_pass_is_quad(idx)) return cmr_wide_queries(idx->dtype, idx->dpad);
@@ -664,9 +675,10 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
         const int left = nq - q0;
         const bool wide = wideq > 0 && left > narrow;          // more than one narrow pass left: go wide
         const int nqp = std::min(wide ? wideq : narrow, left);
+        const bool qp = wide && (quad || short_two_tile_pass(idx, left));
         int rc = enqueue_pass(idx, ws, ws->stream, ws->stream, ws->stream, nullptr, nullptr, nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k, 0,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr, wide && !quad, min_score, wide && quad);
+                              max_dev ? max_dev + q0 : nullptr, wide && !qp, min_score, qp);
         if (rc) return rc;
         q0 += nqp;
     }
@@ -786,6 +798,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         const int left = nq - q0;
         const bool wide = wideq > 0 && left > narrow;
         const int nqp = std::min(wide ? wideq : narrow, left);
+        const bool qp = wide && (quad || short_two_tile_pass(idx, left));
         PipeSlot* sl = &P.slot[P.next++ % (unsigned)P.nslots];
         hipStream_t sp = wide ? wsp : nsp;
         if (sl->used) {
@@ -811,7 +824,7 @@ int search_pipelined_enqueue(cmr_index* idx, const float* q_dev, int nq, int k, 
         int rc = enqueue_pass(idx, &sl->ws, sp, sm, P.sq, sl->pre_done, sl->scan_done, sl->used ? sl->main_done : nullptr, q_dev + (size_t)q0 * idx->dim, nqp, k,
                               (masked && !wide) ? idx->n_cu - P.scan_cus : (masked && wide) ? idx->n_cu - P.wide_cus : idx->reserve_cus,
                               ids_dev + (size_t)q0 * k, scores_dev + (size_t)q0 * k, min_dev ? min_dev + q0 : nullptr,
-                              max_dev ? max_dev + q0 : nullptr, wide && !quad, min_score, wide && quad);
+                              max_dev ? max_dev + q0 : nullptr, wide && !qp, min_score, qp);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(sl->main_done, P.sq));
         sl->used = true;

@@ -291,3 +291,25 @@ def test_ppr_on_a_sharded_passage_index_equals_the_fused_path():
     np.testing.assert_allclose(a, b, rtol=0, atol=1e-13)
     assert np.array_equal(np.argsort(a)[::-1][:50], np.argsort(b)[::-1][:50])
     one.close(); multi.close(); g.close()
+
+
+def test_device_rows_append_equals_host_rows_append():
+    """cmr_mindex_append_dev: rows that live on a device (an encoder's output tensor) are routed like host rows — chunks of
+    shards on that device appended in place — and land under the same global ids."""
+    import torch
+    from comorag_amd.multi_index import MultiDeviceIndex
+    d = 256
+    X = orc.synthetic_corpus(6_000, d, seed=97)
+    Q = orc.synthetic_queries(8, d, seed=98, planted=X)
+    a = MultiDeviceIndex(d, "bf16", devices=[0] * 4, options={"append_block_rows": 128})
+    b = MultiDeviceIndex(d, "bf16", devices=[0] * 4, options={"append_block_rows": 128})
+    at = 0
+    for n in (3_000, 25, 25, 1_000, 1, 1_949):
+        a.append(X[at:at + n])
+        b.append_dev(torch.from_numpy(X[at:at + n]).cuda())
+        at += n
+    assert a.shard_rows() == b.shard_rows() and len(b) == len(X)
+    for x, y in zip(a.search(Q, 20), b.search(Q, 20)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.get_rows(np.arange(0, 6_000, 97)), b.get_rows(np.arange(0, 6_000, 97)))
+    a.close(); b.close()

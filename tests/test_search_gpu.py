@@ -174,9 +174,11 @@ def test_wide_batch_register_resident_queries(dtype, d, nq):
     queries; must equal the oracle and, bit for bit, the multi-pass narrow kernel."""
     X, Q = _mk(40_000 + 17, d, nq, seed=d + nq)
     X[30_000] = X[11]; Q[3] = X[11]
-    a_ids, a_sc = _check(dtype, X, Q, 20)
+    a_ids, a_sc = _check(dtype, X, Q, 20, env={"CMR_WIDE_MODE": "1"})      # the register-resident kernel, whatever the default route of this size is
     b_ids, b_sc = _check(dtype, X, Q, 20, env={"CMR_SCAN_NO_WIDE": "1"})
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
+    c_ids, c_sc = _check(dtype, X, Q, 20)                                  # default: 65 .. 128 queries over a short scan take the query-split grid
+    assert np.array_equal(a_ids, c_ids) and np.array_equal(a_sc, c_sc)
 
 
 @pytest.mark.parametrize("dtype,d,nq", [("bf16", 384, 256), ("f32", 768, 128), ("f32", 200, 97), ("bf16", 512, 65), ("f16", 1536, 200), ("bf16", 768, 256),
