@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--single-process", action="store_true", help="ONE process drives all --gpus devices through MultiDeviceIndex (what hooks.install builds for num_shards = N); no launcher, no collective")
     ap.add_argument("--no-single-process-leg", action="store_true", help="N > 1 under a launcher: skip the single-process leg rank 0 runs afterwards")
     ap.add_argument("--single-process-timeout", type=float, default=300.0)
+    ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the batch-256 / per-rank section may take before the headline line is printed without it")
     return ap.parse_args()
 
 
@@ -506,6 +507,23 @@ def single_process_leg(args):
         return {"error": repr(e)[:300]}
 
 
+def _with_timeout(fn, seconds):
+    """Run fn() on a helper thread; True if it returned within `seconds` (False: it is still stuck — e.g. in a collective whose
+    peer is gone — or it raised)."""
+    import threading
+    box = []
+    def _run():
+        try:
+            fn()
+            box.append(True)
+        except Exception:       # noqa: BLE001
+            box.append(False)
+    th = threading.Thread(target=_run, daemon=True)
+    th.start()
+    th.join(seconds)
+    return bool(box and box[0])
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import torch
@@ -606,40 +624,68 @@ def main():
         out["verified"]["error"] = "pipelined outputs differ from the synchronous search of the same batch"
 
     # BASELINE config 3 as written: the same (sharded) corpus, batch 256 — one corpus pass of the wide kernel per batch
+    # (multi-rank: this section holds the FIRST executions of the library's own RCCL communicator on real hardware — it runs under a
+    #  watchdog, so that a collective that never returns costs the extras, not the headline line above)
     c3 = None
     same_w = True
     q256 = None
-    if not args.no_extra and args.batch != 256 and args.dim in (768, 1024):
-        q256 = make_queries(torch, max(1, min(args.query_batches, 3)), 256, args.dim, device, 8765)
-        steps_w = max(10, args.steps // 2)
-        shw = sh.view(ex256, timing=world > 1) if world > 1 else sh
-        dtw, profw, lastw, qiw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl)
-        _, _, same_w = verify_last_batch(shw, lastw, q256[qiw].cpu().numpy(), args.k)
-        c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_wide_active")))
-        c3["kernel"] = "scan_wide_kernel (256 queries resident in registers, LDS-DMA corpus ring)"
-        c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
-        c3["last_pipelined_batch_equals_synchronous_search"] = same_w
-        c3["exchange_binding"] = ex256 if world > 1 else None
-        if world > 1 and args.backend == "nccl":
-            try:
-                c3["rccl_ranks_seen"] = (shw if ex256 == "cabi" else sh).comm_info()["rccl_ranks_seen"]
-            except Exception as e:
-                c3["rccl_ranks_seen"] = repr(e)[:200]
+    shw = sh
+    section_error = []
+
+    def _after_headline():
+        nonlocal c3, same_w, q256, shw
+        torch.cuda.set_device(device)
+        if not args.no_extra and args.batch != 256 and args.dim in (768, 1024):
+            q256 = make_queries(torch, max(1, min(args.query_batches, 3)), 256, args.dim, device, 8765)
+            steps_w = max(10, args.steps // 2)
+            shw = sh.view(ex256, timing=world > 1) if world > 1 else sh
+            dtw, profw, lastw, qiw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl)
+            _, _, same_w = verify_last_batch(shw, lastw, q256[qiw].cpu().numpy(), args.k)
+            c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_wide_active")))
+            c3["kernel"] = "scan_wide_kernel (256 queries resident in registers, LDS-DMA corpus ring)"
+            c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
+            c3["last_pipelined_batch_equals_synchronous_search"] = same_w
+            c3["exchange_binding"] = ex256 if world > 1 else None
+            if world > 1 and args.backend == "nccl":
+                try:
+                    c3["rccl_ranks_seen"] = (shw if ex256 == "cabi" else sh).comm_info()["rccl_ranks_seen"]
+                except Exception as e:
+                    c3["rccl_ranks_seen"] = repr(e)[:200]
+        if world > 1:
+            out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] = same_w
+            out["exchange_bindings"] = {"batch64": ex64, "batch256": ex256 if c3 else None, "backend": args.backend, "share_device": bool(args.share_device),
+                                        "torch_world_size": dist.get_world_size()}
+            if args.backend == "nccl":
+                try:        # ranks RCCL itself reports for the library's own communicator (ncclCommCount)
+                    cv = sh if ex64 == "cabi" else (shw if c3 else sh.view("cabi"))
+                    out["exchange_bindings"]["rccl_ranks_seen"] = cv.comm_info()["rccl_ranks_seen"]
+                except Exception as e:
+                    out["exchange_bindings"]["rccl_ranks_seen"] = repr(e)[:200]
+            mine = {"rank": rank, "rows": len(sh), "device": str(device), "batch64": {k_: head.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")},
+                    "batch256": {k_: c3.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
+            box = [None] * world
+            dist.all_gather_object(box, mine)
+            out["per_rank"] = box
+
     if world > 1:
-        out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] = same_w
-        out["exchange_bindings"] = {"batch64": ex64, "batch256": ex256 if c3 else None, "backend": args.backend, "share_device": bool(args.share_device),
-                                    "torch_world_size": dist.get_world_size()}
-        if args.backend == "nccl":
-            try:        # ranks RCCL itself reports for the library's own communicator (ncclCommCount)
-                cv = sh if ex64 == "cabi" else (shw if c3 else sh.view("cabi"))
-                out["exchange_bindings"]["rccl_ranks_seen"] = cv.comm_info()["rccl_ranks_seen"]
-            except Exception as e:
-                out["exchange_bindings"]["rccl_ranks_seen"] = repr(e)[:200]
-        mine = {"rank": rank, "rows": len(sh), "device": str(device), "batch64": {k_: head.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")},
-                "batch256": {k_: c3.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
-        box = [None] * world
-        dist.all_gather_object(box, mine)
-        out["per_rank"] = box
+        import threading
+        def _guarded():
+            try:
+                _after_headline()
+            except Exception as e:      # noqa: BLE001
+                section_error.append(repr(e)[:400])
+        th = threading.Thread(target=_guarded, daemon=True)
+        th.start()
+        th.join(args.extras_timeout)
+        if th.is_alive() or section_error:
+            why = section_error[0] if section_error else f"no return after {args.extras_timeout:.0f} s (a collective of the batch-256 / per-rank section never completed)"
+            out["extra"] = {"config3_batch256": {"error": why}}
+            out["multi_rank_extras"] = "abandoned: " + why
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)                 # ranks may sit in a dead collective: no further collectives, no clean teardown
+    else:
+        _after_headline()
     rows_here = len(sh)
     if world > 1 and c3 and shw is not sh:
         shw.close()
@@ -777,19 +823,28 @@ def main():
                 "corpus_embed_bf16_chunks_per_s": _get(extra, "corpus_embed_bf16", "value"),
                 "single_query_latency_1M_rows_us": _get(extra, "single_query_latency", "rows", str(min(args.rows, 1_000_000)))}
         out["config"].update({f"x_{k_}": v_ for k_, v_ in flat.items() if v_ is not None})
+    left_cleanly = True
     if world > 1:
         # every rank has freed its shard; the ranks leave the group BEFORE rank 0 starts the single-process leg, so that no
-        # collective is pending while ONE child process takes all the GPUs
-        torch.cuda.synchronize(device)
-        dist.barrier()
-        dist.destroy_process_group()
-        if rank == 0 and not args.no_single_process_leg:
+        # collective is pending while ONE child process takes all the GPUs (under a watchdog: a peer that died in the section
+        # above must not keep the line from being printed)
+        def _leave():
+            torch.cuda.set_device(device)
+            torch.cuda.synchronize(device)
+            dist.barrier()
+            dist.destroy_process_group()
+        left_cleanly = _with_timeout(_leave, 120.0)
+        if rank == 0 and not args.no_single_process_leg and left_cleanly:
             torch.cuda.empty_cache()
             out["single_process"] = single_process_leg(args)
             if isinstance(out["single_process"].get("value"), float):
                 out["config"]["x_single_process_qps"] = out["single_process"]["value"]
+        elif rank == 0 and not left_cleanly:
+            out["single_process"] = {"error": "skipped: the ranks did not leave the process group within 120 s"}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if not left_cleanly:
+        os._exit(0 if (same and same_w) else 1)
     if not (same and same_w):
         raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
 
