@@ -37,7 +37,7 @@ if os.environ.get("CMR_BUILD_LIB"):          # experiment builds go to their own
 # unrolled size exceeds LLVM's default limit for "#pragma unroll" (16 K) and hipcc silently keeps the loops.
 SCAN_FLAGS = ["-mllvm", "-pragma-unroll-threshold=1048576"]
 SOURCES = ["scan_kernels.hip", "aux_kernels.hip", "api.hip", "comm.hip", "ppr.hip", "encoder_kernels.hip", "multi.hip"]
-HEADERS = ["cmr_device.h", "cmr_kernels.h", "cmr_internal.h", os.path.join("..", "..", "include", "comorag_hip.h")]
+HEADERS = ["cmr_device.h", "cmr_kernels.h", "cmr_internal.h", "cmr_select.h", os.path.join("..", "..", "include", "comorag_hip.h")]
 
 _KERNEL_RE = re.compile(r"^_Z11scan_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEv5ScanP:")
 
@@ -51,13 +51,56 @@ def _regs(text: str) -> set:
     return out
 
 
+_LABEL_RE = re.compile(r"^(?:\.L(BB\d+_\d+):|; %bb\.\d+:)")
+
+
+def _ring_loop_membership(body: list, ring_line: int) -> list:
+    """Per line of a kernel body: does it belong to the loop that holds the asm ring loads (line `ring_line` is one of them)?
+    LLVM annotates every block with its innermost loop header ('in Loop: Header=BBx_y') and every loop header with its parents
+    ('Parent Loop BBx_y'); blocks are laid out in any order (cold blocks of the loop may follow the code behind it)."""
+    block_of = [None] * len(body)       # line -> (own label, innermost header, is_header, parents)
+    cur = (None, None, False, ())
+    parents_of = {}
+    n = 0
+    while n < len(body):
+        m = _LABEL_RE.match(body[n].strip())
+        if m:
+            label = m.group(1)
+            notes = [body[n]]
+            j = n + 1
+            while j < len(body) and body[j].strip().startswith(";") and not body[j].strip().startswith(";;#") and not _LABEL_RE.match(body[j].strip()):
+                notes.append(body[j])
+                j += 1
+            text = " ".join(notes)
+            is_header = "Loop Header" in text
+            hm = re.search(r"in Loop: Header=(BB\d+_\d+)", text)
+            parents = tuple(re.findall(r"Parent Loop (BB\d+_\d+)", text))
+            header = label if is_header else (hm.group(1) if hm else None)
+            if is_header and label:
+                parents_of[label] = parents
+            cur = (label, header, is_header, parents)
+        block_of[n] = cur
+        n += 1
+    if ring_line < 0 or block_of[ring_line] is None or block_of[ring_line][1] is None:
+        return [True] * len(body)         # cannot tell: treat everything as inside (the strict rule)
+    h = block_of[ring_line][1]
+    outer = parents_of.get(h, ())
+    main = outer[0] if outer else h        # the outermost loop around the ring loads
+    def inside(b):
+        if b is None or b[1] is None:
+            return False
+        return b[1] == main or main in parents_of.get(b[1], ())
+    return [inside(b) for b in block_of]
+
+
 def audit_ring(asm_text: str) -> dict:
     """For every scan_kernel<..., ASMRING=1> in the gfx950 assembly decide whether the hand-counted
     load ring is safe: the ring's VGPRs (destinations of the global_load_dwordx4 inside
     ;;#ASMSTART/;;#ASMEND) may be written only by that asm and read only by v_mfma; any other
     compiler instruction touching them after the first ring load (a copy, a spill, a reuse)
-    could observe a slot before its data landed (cdna guide §5.7 item 1).  Also requires zero
-    scratch.  Returns {(dt,nqt,cap,ring,mode): bool}."""
+    could observe a slot before its data landed (cdna guide §5.7 item 1).  Code that is outside the ring
+    loop AND behind a compiler `s_waitcnt vmcnt(0)` that follows the loop (the fence in front of the kernel's tail) may reuse
+    them: nothing is in flight there.  Also requires zero scratch.  Returns {(dt,nqt,cap,ring,mode): bool}."""
     result = {}
     lines = asm_text.split("\n")
     i = 0
@@ -77,7 +120,8 @@ def audit_ring(asm_text: str) -> dict:
             continue
         in_asm = False
         ring_regs: set = set()
-        for l in body:
+        last_ring_load = -1
+        for n, l in enumerate(body):
             s = l.strip()
             if s.startswith(";;#ASMSTART"):
                 in_asm = True
@@ -85,10 +129,13 @@ def audit_ring(asm_text: str) -> dict:
                 in_asm = False
             elif in_asm and s.startswith("global_load_dwordx4"):
                 ring_regs |= _regs(s.split(",")[0])
+                last_ring_load = n
         ok = len(ring_regs) == 4 * ring
+        in_ring_loop = _ring_loop_membership(body, last_ring_load)
         loaded: set = set()   # ring registers that already received an asm load
         in_asm = False
-        for l in body:
+        drained = False       # behind the ring loop AND behind a compiler s_waitcnt vmcnt(0): no ring load is in flight any more
+        for n, l in enumerate(body):
             s = l.strip()
             if not s or (s.startswith(";") and not s.startswith(";;#ASM")):
                 continue
@@ -101,11 +148,19 @@ def audit_ring(asm_text: str) -> dict:
             if in_asm:
                 if s.startswith("global_load_dwordx4"):
                     loaded |= _regs(s.split(",")[0])
+                elif n > last_ring_load and not in_ring_loop[n] and re.match(r"s_waitcnt\s+vmcnt\(0\)", s):
+                    drained = True      # the kernel's own drain statement behind the loop (it holds every ring slot)
                 continue
             if "scratch_" in s:
                 ok = False
             code = s.split(";")[0]
-            if _regs(code) & loaded:
+            if n > last_ring_load and not in_ring_loop[n] and re.match(r"s_waitcnt\s+vmcnt\(0\)", code):
+                drained = True
+            if drained and not in_ring_loop[n]:
+                continue          # code behind the loop (the finishing stage's selection) may reuse the registers
+            # inside the ring loop every ring register is in flight at every point (the loads of the previous iteration): the
+            # textual order says nothing there; in front of / behind the loop it does
+            if _regs(code) & (ring_regs if in_ring_loop[n] else loaded):
                 if code.startswith("v_mfma"):
                     if _regs(code.split(",")[0]) & ring_regs:
                         ok = False
@@ -223,10 +278,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
             f.write("// generated by comorag_amd/build.py from the gfx950 assembly of scan_kernels.hip\n"
                     "struct Row { int dt, nqt, cap, ring, mode, ok; };\n"
                     f"static const Row kRows[] = {{\n{rows}\n}};\n"
-                    "bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring) {\n"
+                    "// mode: 0 = top-k, 1 = all scores (no candidate lists: cap does not matter), 2 = top-k with the finishing stage\n"
+                    "bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring, int mode) {\n"
                     "    bool any = false;\n"
                     "    for (const Row& r : kRows)\n"
-                    "        if (r.dt == dtype && r.nqt == nqt && r.ring == ring && (r.mode == 1 || r.cap == cap)) {\n"
+                    "        if (r.dt == dtype && r.nqt == nqt && r.ring == ring && r.mode == mode && (r.mode == 1 || r.cap == cap)) {\n"
                     "            if (!r.ok) return false;\n"
                     "            any = true;\n"
                     "        }\n"

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <numeric>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -24,7 +25,7 @@
 #define CMR_SCAN_WAVES 8
 #define CMR_CORPUS_SLACK (128 * 1024)
 
-bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring);  // ring_audit.cpp (generated at build)
+bool cmr_ring_audit_ok(int dtype, int nqt, int cap, int ring, int mode);  // ring_audit.cpp (generated at build); mode: 0 top-k, 1 scores, 2 top-k with the finishing stage
 static const long long kMaxMergeLists = 4096;                    // merge_query_kernel: W <= 16 * MERGE_THREADS
 
 namespace {
@@ -79,6 +80,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf qfrag, lists, cnt, mm, flag, tau, s_lists, s_cnt, s_mm, arrive;
+    DevBuf fin_ctl, fin_pmax, fin_tau, fin_dense, fin_mm;      // scan with the finishing stage (cmr_launch_scan_fin)
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
     // synchronous search: queries in, (ids | scores | min | max | non-finite flag) out through ONE pinned host buffer and
@@ -102,6 +104,7 @@ struct Workspace {
     void release() {
         qfrag.release(); lists.release(); cnt.release(); mm.release(); flag.release(); tau.release();
         s_lists.release(); s_cnt.release(); s_mm.release(); arrive.release();
+        fin_ctl.release(); fin_pmax.release(); fin_tau.release(); fin_dense.release(); fin_mm.release();
         d_q.release(); d_ids.release(); d_scores.release(); d_min.release(); d_max.release(); d_cand.release(); d_out.release();
         d_pack.release();
         if (h_pin) (void)hipHostFree(h_pin);
@@ -175,6 +178,13 @@ struct cmr_index {
     int wide_mode = 0;       // wide_mode: batches of more than one narrow pass — 1: the register-resident wide kernel, 2: the query-split grid of the
                              // narrow kernel (up to 4 query tiles walk the same panel ranges on CUs of one XCD; any dim / dtype), 0: the measured default
     int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
+    int scan_fin = 1;        // scan_fin = 0: small synchronous batches on corpora beyond the single-launch path run the sampling / scan / merge chain
+                             // instead of the scan with the finishing stage (thresholds and final selection inside the scan launch)
+    int fin_dense = 4096;    // scan_fin_dense: keys per query of the finishing stage's dense candidate lists (~k x panels / 1024 beat a threshold taken
+                             // from 1024 first panels: 600 at 1 M rows, 6 K at 10 M; a list that overflows hands the selection to the merge launch)
+    int fin_spin = 0;        // scan_fin_spin: rounds of ~1.5 us the workgroups that do not supply thresholds wait for them before they scan without (0: they look once)
+    int fin_max_q = 4;       // scan_fin_queries: largest batch the finishing stage takes (<= 32; one wave derives the thresholds query by query: measured at 768-d bf16,
+                             // 1 M rows — 1 / 2 / 4 queries 270 / 284 / 301 us against 302 / 315 / 337 for the chain, 8 queries 362 against 338)
     int dual_wide_active = 0;   // read-only ("pipe_dual_scan_wide_active"): the same for the last wide pass
     int dual_active = 0;     // read-only ("pipe_dual_scan_active"): did the last pipelined <= 64-query pass alternate between the two scan streams
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
@@ -213,6 +223,10 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "sample_single") idx->single_level = (int)v;
     else if (n == "sample_single_max") idx->single_level_max = std::max<long long>(0, v);
     else if (n == "sample_tau_in_scan") idx->tau_in_scan = (int)v;
+    else if (n == "scan_fin") idx->scan_fin = (int)v;
+    else if (n == "scan_fin_dense") idx->fin_dense = (int)std::max<long long>(1, std::min<long long>(v, 1 << 16));
+    else if (n == "scan_fin_spin") idx->fin_spin = (int)std::max<long long>(0, std::min<long long>(v, 1000));
+    else if (n == "scan_fin_queries") idx->fin_max_q = (int)std::max<long long>(1, std::min<long long>(v, 32));
     else if (n == "sample_div") idx->sample_div = (int)std::max<long long>(2, v);
     else if (n == "sample_maxmul") idx->sample_maxmul = (int)std::max<long long>(0, v);
     else if (n == "pipe_reserve_cus") idx->reserve_cus = (int)v;
@@ -233,7 +247,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 // development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
-                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "sample_div", "sample_maxmul", "pipe_reserve_cus",
                                   "pipe_slots", "wide_waves", "wide_mode", "stream_nt", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
@@ -353,9 +367,10 @@ int make_geom(cmr_index* idx, int nq, int k, bool topk, CmrScanGeom* g) {
     const int ks = idx->dtype == CMR_F32 ? idx->dpad / 8 : idx->dpad / 16;
     g->ring = (ks % 16 == 0) ? 16 : 8;
     if (idx->force_ring == 8 || (idx->force_ring == 16 && ks % 16 == 0)) g->ring = idx->force_ring;
-    g->asm_ring = cmr_ring_audit_ok(g->dtype, g->nqt, g->cap, g->ring) ? 1 : 0;
+    const int mode = topk ? 0 : 1;
+    g->asm_ring = cmr_ring_audit_ok(g->dtype, g->nqt, g->cap, g->ring, mode) ? 1 : 0;
     if (idx->force_asm == 0) g->asm_ring = 0;
-    if (idx->force_asm == 1 && !cmr_ring_audit_ok(g->dtype, g->nqt, g->cap, g->ring))
+    if (idx->force_asm == 1 && !cmr_ring_audit_ok(g->dtype, g->nqt, g->cap, g->ring, mode))
         return fail(CMR_ERR_UNSUPPORTED, "CMR_SCAN_ASM_RING=1 but variant (dtype %d nqt %d cap %d ring %d) failed the ISA audit", g->dtype, g->nqt, g->cap, g->ring);
     if (!cmr_scan_geom(g)) return fail(CMR_ERR_UNSUPPORTED, "scan geometry does not fit LDS (dpad %d nqt %d)", idx->dpad, g->nqt);
     const long long npanels = (idx->n + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS;
@@ -435,6 +450,17 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     // the groups' twins re-read each corpus block from L2: default cache policy for them, non-temporal for single-group scans
     g.stream_default_policy = idx->stream_nt < 0 ? (G > 1 ? 1 : 0) : (idx->stream_nt ? 0 : 1);
     const int lists_per_wg = wide ? 1 : CMR_SCAN_WAVES;
+    // A synchronous caller's handful of queries (everything on ONE stream) on a corpus beyond the single-launch path: the scan
+    // with the finishing stage — no sampling launches, no merge of its own (scan_kernel MODE_FIN; 2 M x 768 bf16 rows, one
+    // query: pack 5 + sample 15 + scan 471 + merge 46 us before, pack + scan with ~10 us of finishing after)
+    bool fin = idx->scan_fin && !idx->no_sample && !wide && G == 1 && !min_score && sp == sm && sm == sq && g.nqt == 1 && nqp <= idx->fin_max_q &&
+               k <= 64 && npanels >= 4096 && npanels >= (long long)idx->n_cu * 2 * CMR_SCAN_WAVES;      // (every wave of the grid has a first panel)
+    if (fin) {
+        const bool ok = cmr_ring_audit_ok(g.dtype, 1, g.cap, g.ring, 2);
+        if (idx->force_asm == 1 && !ok) fin = false;       // the caller insists on the hand-counted ring: only audited variants
+        if (g.lds + CMR_FIN_LDS > 160 * 1024 || g.grid > 512) fin = false;
+        else g.asm_ring = (ok && idx->force_asm != 0) ? 1 : 0;
+    }
     // Sampling passes (large corpora).  Level i scans S_i strided panels and takes the exact k-th
     // best of that sample per query as the threshold of the next level / of the main scan.  Any
     // subset's k-th best is a valid lower bound of the global k-th best, so results are unchanged;
@@ -449,7 +475,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     bool single_level = false;
     // threshold search (min_score): the caller's bound is the initial threshold of every query — already selective, so no
     // sampling passes
-    if (!idx->no_sample && npanels >= 256 && !min_score) {
+    if (!idx->no_sample && npanels >= 256 && !min_score && !fin) {
         const long long s0 = std::max<long long>(16, k);                       // panels
         // A handful of queries on a mid-size corpus (what a synchronous caller issues) is a chain of dependent launches
         // around a short scan: ONE sampling level of 128 panels instead of two saves a scan + merge pair (~45 us of a
@@ -594,7 +620,30 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(hipEventRecord(pe.a, sm));
     }
     if (G > 1) g.grid *= G;
-    HIP_TRY(wide ? cmr_launch_scan_wide(g, a, sm) : cmr_launch_scan_topk(g, a, sm));
+    const int* fin_state = nullptr;
+    if (fin) {
+        const int kFinDenseCap = idx->fin_dense;
+        if (!ws->fin_ctl.p) {                   // zeroed once; the kernel's last workgroup re-arms the words
+            HIP_TRY(ws->fin_ctl.ensure(CMR_FIN_CTL * sizeof(int)));
+            HIP_TRY(hipMemsetAsync(ws->fin_ctl.p, 0, CMR_FIN_CTL * sizeof(int), sm));
+        }
+        HIP_TRY(ws->fin_pmax.ensure((size_t)32 * CMR_FIN_SLOTS * 8));
+        HIP_TRY(ws->fin_tau.ensure(32 * 8));
+        HIP_TRY(ws->fin_mm.ensure((size_t)32 * 512 * 8));
+        a.fin_mm = (u64*)ws->fin_mm.p;
+        HIP_TRY(ws->fin_dense.ensure((size_t)32 * kFinDenseCap * 8));
+        a.fin = (int*)ws->fin_ctl.p; a.fin_pmax = (u64*)ws->fin_pmax.p; a.fin_tau = (u64*)ws->fin_tau.p; a.fin_dense = (u64*)ws->fin_dense.p;
+        a.fin_wgs = std::min(CMR_FIN_SLOTS / CMR_SCAN_WAVES, g.grid);
+        // the golden-ratio multiple of the grid, moved to the next value coprime with it: the first fin_wgs workgroups' ranges spread evenly
+        a.fin_mul = 1;
+        for (int m = std::max(1, (int)(g.grid * 0.6180339887)); m < g.grid; ++m)
+            if (std::gcd(m, g.grid) == 1) { a.fin_mul = m; break; }
+        a.fin_dcap = kFinDenseCap;
+        a.fin_spin = idx->fin_spin;
+        a.out_ids = ids_dev; a.out_scores = scores_dev; a.out_min = min_dev; a.out_max = max_dev; a.id_base = kernel_id_base(idx);
+        fin_state = (const int*)ws->fin_ctl.p + CMR_FIN_STATE;
+    }
+    HIP_TRY(wide ? cmr_launch_scan_wide(g, a, sm) : fin ? cmr_launch_scan_fin(g, a, sm) : cmr_launch_scan_topk(g, a, sm));
     if (prof) {
         HIP_TRY(hipEventRecord(pe.b, sm));
         std::lock_guard<std::mutex> pg(idx->prof_mu);
@@ -606,7 +655,7 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         HIP_TRY(hipStreamWaitEvent(sq, ev_scan, 0));
     }
     HIP_TRY(cmr_launch_merge_query((const u64*)ws->lists.p, (const int*)ws->cnt.p, W, NQ, g.cap, nqp, k, (const float2*)ws->mm.p,
-                                   kernel_id_base(idx), ids_dev, scores_dev, min_dev, max_dev, nullptr, sq, G > 1));
+                                   kernel_id_base(idx), ids_dev, scores_dev, min_dev, max_dev, nullptr, sq, G > 1, fin_state));
     return remap_ids_enqueue(idx, ids_dev, (long long)nqp * k, sq);
 }
 

@@ -55,10 +55,40 @@ struct CmrScanArgs {
     // narrow kernel, query-split grid: qgroups x (geom.grid) workgroups, group g scans the whole corpus for queries
     // g*nqt*32 ..; qfrag holds qgroups*nqt tiles, lists / cnt / mm are [qgroups][W][nqt*32](..), tau_init [qgroups][nqt*32]
     int qgroups;
+    // narrow kernel with the finishing stage (cmr_launch_scan_fin): control words (CMR_FIN_CTL ints, zeroed once — the kernel re-arms
+    // them), first-panel maxima [32][fin_ns], thresholds [32], dense candidate lists [32][fin_dcap], and the search's outputs
+    int* fin;
+    u64* fin_pmax;
+    u64* fin_tau;
+    u64* fin_dense;
+    u64* fin_mm;          // [32][grid] scratch
+    int fin_wgs;          // workgroups (the first dispatched) whose waves' first panels supply the thresholds: 8 x fin_wgs <= CMR_FIN_SLOTS maxima
+    int fin_mul;          // workgroup b scans the panel ranges of virtual workgroup (b x fin_mul) mod grid (coprime with the grid; 1 = identity)
+    int fin_dcap;
+    int fin_spin;         // rounds (~1.5 us each) the other workgroups give the suppliers before they start without thresholds
+    int64_t* out_ids;
+    float* out_scores;
+    float* out_min;
+    float* out_max;
+    long long id_base;
 };
+// control words (ints) — every counter on a 128-byte line of its own: device atomics on one line serialise
+#define CMR_FIN_DONE 0        // workgroups whose waves have all published their first-panel maxima
+#define CMR_FIN_READY 32      // thresholds published
+#define CMR_FIN_WGS 64        // workgroups finished
+#define CMR_FIN_STATE 96      // result state: 1 = the scan wrote the final results itself, 2 = a list overflowed (the merge launch decides)
+#define CMR_FIN_OVER 128      // some workgroup's staging area overflowed
+#define CMR_FIN_DBG 136
+#define CMR_FIN_DCNT(q) (160 + 32 * (q))     // dense list lengths
+#define CMR_FIN_CTL (160 + 32 * 32)
+#define CMR_FIN_LDS 2048      // bytes of LDS the finishing stage adds to the geometry's (the waves' min / max)
+#define CMR_FIN_SLOTS 1024    // first-panel maxima the thresholds are taken from (one selection chunk of a wave)
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
 hipError_t cmr_launch_scan_scores(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
+// top-k scan of <= 32 queries (k <= 64) that also derives its thresholds (no sampling launch) and selects the final k best per
+// query (no merge launch); a.fin[CMR_FIN_STATE] tells the merge launch behind it whether anything is left to do
+hipError_t cmr_launch_scan_fin(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
 // wide-batch (register-resident queries) top-k scan: 4 waves x 2 (768-d) or 1 (1024-d) tiles of 32 queries;
 // in sampling mode (sample_waves > 0) the grid's workgroups split the sample_waves strided panels among them
 hipError_t cmr_launch_scan_wide(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);
@@ -78,7 +108,8 @@ hipError_t cmr_launch_convert_rows(int dtype, const float* rows, long long n, in
 // grouped = true: the lists come from a query-split scan ([group][W][nq_stride]): query q reads group q / nq_stride
 hipError_t cmr_launch_merge_query(const u64* lists, const int* cnt, int W, int nq_stride, int cap, int nq, int k,
                                   const float2* mm, long long id_base, int64_t* out_ids, float* out_scores,
-                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s, bool grouped = false);
+                                  float* out_min, float* out_max, u64* out_tau, hipStream_t s, bool grouped = false,
+                                  const int* skip_if_one = nullptr);      // device word: 1 = the results are final already (cmr_launch_scan_fin), return at once
 // whole search of a small corpus in one launch (nq <= 16): kind 1 = <= 32 panels, kind 2 = hierarchical (up to max_panels panels,
 // k <= 64; needs the arrival counter), 0 = not applicable.  `arrive`: a zeroed device int the launches of
 // one stream share (nullptr: single-workgroup flat path only).

@@ -27,9 +27,14 @@
 
 #include "cmr_device.h"
 #include "cmr_kernels.h"
+#include "cmr_select.h"
 
 #define MODE_TOPK 0
 #define MODE_SCORES 1
+// MODE_FIN: top-k with the thresholds AND the final selection inside the launch (a synchronous caller's handful of queries on a
+// mid-size or large corpus: the sampling scan, its merge and the candidate merge are a chain of dependent launches around a
+// short scan there) — see "finishing stage" in scan_kernel
+#define MODE_FIN 2
 
 // Cache policy of the corpus stream's loads: non-temporal.  Every byte of the corpus is read once per launch by one CU,
 // so keeping the lines in L2 / MALL only evicts what the other kernels of the pipeline use; measured with
@@ -73,6 +78,18 @@ struct ScanP {
     const int* scnt;
     int sW;
     int qgroups;           // > 1: query-split grid (see scan_kernel): gridDim.x = qgroups x virtual grid, every group has its own query tile
+    // MODE_FIN
+    int* fin;              // control words (cmr_kernels.h: CMR_FIN_*), every counter on a 128-byte line of its own
+    u64* fin_pmax;         // [32][8 * fin_wgs] per-query maxima of the first panels of the first fin_wgs workgroups' waves
+    u64* fin_tau;          // [32] published thresholds
+    u64* fin_dense;        // [32][fin_dcap] the candidates that beat their wave's final threshold
+    u64* fin_mm;           // [32][grid] (min, max) per workgroup
+    int fin_wgs, fin_mul, fin_dcap, fin_spin;
+    int64_t* out_ids;
+    float* out_scores;
+    float* out_min;
+    float* out_max;
+    long long id_base;
 };
 
 // Slow path, part 1 (inline, a handful of registers, no waits on global memory): push the keys of
@@ -140,7 +157,9 @@ __device__ __forceinline__ void topk_compact(u64 need, int k, u64& tau_key, floa
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         if (n >= k) {
             const u64 nt = stage[CAP];
-            if (ql == j) { tau_key = nt; tau_f = cmr_key_score(nt); }
+            // (never downwards: with the finishing stage a list still holds what the wave pushed before it adopted the published
+            // threshold — the k-th best of THAT is no bound worth having)
+            if (ql == j && nt > tau_key) { tau_key = nt; tau_f = cmr_key_score(nt); }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
@@ -162,12 +181,19 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
     const int KS = P.ks;
     constexpr int NQ = NQT * 32;
+    constexpr bool TOPK = MODE != MODE_SCORES;
+    constexpr bool FIN = MODE == MODE_FIN;
+    static_assert(!FIN || NQT == 1, "the finishing stage handles one query tile");
 
     v4u* qf = reinterpret_cast<v4u*>(smem);
     int* cnt_all = reinterpret_cast<int*>(smem + (size_t)NQT * KS * 1024);
     u64* stage_all = reinterpret_cast<u64*>(cnt_all + CMR_SCAN_WAVES * NQ);
     int* cnt_w = cnt_all + wave * NQ;
     u64* stage = stage_all + wave * (CAP + 2);
+    // FIN only (the launcher adds CMR_FIN_LDS bytes): the waves' min / max per query, reduced per workgroup at the end
+    float2* fin_mmw = reinterpret_cast<float2*>(stage_all + CMR_SCAN_WAVES * (CAP + 2) + 2);      // [waves][32]
+    int* fin_sh = reinterpret_cast<int*>(stage_all + CMR_SCAN_WAVES * (CAP + 2));     // FIN: [0] the workgroup's ticket, [1] a staging area overflowed, [2] waves past their first panel
+    // (dynamic LDS on purpose: the function's dynamic limit is the whole 160 KiB, a static variable on top of it fails the launch)
 
     // Query-split grid (batches of more than NQ queries in ONE corpus pass): the grid is qgroups x a virtual grid; the
     // workgroups of group g hold query tile g (queries g*NQ ..) in LDS and walk the SAME per-wave panel ranges as their
@@ -187,13 +213,18 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             bid -= grp * vgrid;
         }
     }
+    // FIN: the workgroups that are dispatched first supply the thresholds (their first panels); a multiplicative permutation of the
+    // workgroup ids spreads their panel ranges over the whole corpus (rows arrive document by document: a sample of one region
+    // would be valid but loose)
+    if constexpr (FIN) bid = (int)(((long long)bid * P.fin_mul) % (long long)gridDim.x);
     const int nq_g = P.nq - grp * NQ;          // queries of this group (the last group may be ragged)
     {
         const v4u* qsrc = P.qfrag + (size_t)grp * NQT * KS * 64;
         for (int i = tid; i < NQT * KS * 64; i += CMR_SCAN_THREADS) qf[i] = qsrc[i];
     }
-    if (MODE == MODE_TOPK)
+    if (TOPK)
         for (int i = tid; i < CMR_SCAN_WAVES * NQ; i += CMR_SCAN_THREADS) cnt_all[i] = 0;
+    if (FIN && tid == 0) { fin_sh[1] = 0; fin_sh[2] = 0; }
     __syncthreads();
 
     const int W = vgrid * CMR_SCAN_WAVES;
@@ -254,12 +285,12 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         rmax[t] = -__builtin_inff();
         tau_f[t] = -__builtin_inff();
         tau_key[t] = 0ull;
-        if (MODE == MODE_TOPK) {
+        if (TOPK) {
             const int q = t * 32 + (lane & 31);
             if (q >= nq_g) {                     // padding query (all-zero operand): nothing may pass
                 tau_key[t] = ~0ull;
                 tau_f[t] = __builtin_inff();
-            } else if (NQT == 1 && P.slists) {   // derived above from the sampling pass's lists (q < nq <= 8 waves)
+            } else if (!FIN && NQT == 1 && P.slists) {   // derived above from the sampling pass's lists (q < nq <= 8 waves)
                 tau_key[t] = stage_all[(size_t)q * (CAP + 2) + CAP + 1];
                 if (tau_key[t]) tau_f[t] = cmr_key_score(tau_key[t]);
             } else if (P.tau_init) {             // a valid lower bound on the global k-th best key
@@ -268,7 +299,36 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             }
         }
     }
-    u64* list_w = (MODE == MODE_TOPK) ? P.lists + gwl * NQ * CAP : nullptr;
+    u64* list_w = TOPK ? P.lists + gwl * NQ * CAP : nullptr;
+    int fin_phase = 0;      // FIN: 0 = first panel pending, 1 = waiting for the published thresholds, 2 = adopted
+    if constexpr (FIN) {
+        // The workgroups that do not supply the thresholds look for them before they start: the second round of workgroups (a CU
+        // holds one at a time) finds them published and never scans without.  fin_spin > 0 makes wave 0 look again every ~1.5 us
+        // for that many rounds — a BOUNDED wait on workgroups that were dispatched earlier and wait for nobody, so it cannot
+        // deadlock — but the head start does not pay: half the CUs idle while the suppliers' first panels stream at half the
+        // rate (2 M rows, one query: scan 546 us with 40 rounds, 518 with none).
+        if ((int)blockIdx.x >= P.fin_wgs) {
+            if (wave == 0) {
+                int rdy = 0;
+                for (int spin = 0;; ++spin) {
+                    rdy = __hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (rdy || spin >= P.fin_spin) break;
+                    __builtin_amdgcn_s_sleep(48);
+                }
+                if (lane == 0) fin_sh[3] = rdy;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            fin_phase = 1;
+            if (fin_sh[3]) {
+                const int q = lane & 31;
+                const u64 gt = q < nq_g ? __hip_atomic_load(&P.fin_tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                if (q < nq_g && gt > tau_key[0]) { tau_key[0] = gt; tau_f[0] = cmr_key_score(gt); }
+                fin_phase = 2;
+            }
+        }
+    }
 
     if (p1 > p0) {
         // The ring always prefetches R blocks ahead, also past the end of this wave's range: the
@@ -293,7 +353,15 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     if constexpr ((u) < R) {                                                                               \
         if constexpr (ASMRING) {                                                                           \
             v4u slot_ = buf[(u)];                                                                        \
-            if constexpr (POL)                                                                             \
+            /* NQT == 1: the accumulator rides along as a second tied operand — with ONE MFMA per slot LLVM otherwise sinks the   */ \
+            /* MFMAs below the reloads and keeps each slot alive in a COPY made before its wait (stale data; build.py's audit)    */ \
+            if constexpr (NQT == 1 && POL)                                                                 \
+                asm volatile("global_load_dwordx4 %0, %2, %3 offset:%4" CMR_STREAM_POLICY                  \
+                             : "+v"(slot_), "+v"(acc[0]) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
+            else if constexpr (NQT == 1)                                                                   \
+                asm volatile("global_load_dwordx4 %0, %2, %3 offset:%4"                                    \
+                             : "+v"(slot_), "+v"(acc[0]) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
+            else if constexpr (POL)                                                                        \
                 asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" CMR_STREAM_POLICY                  \
                              : "+v"(slot_) : "v"(voff[(u) >> 2]), "s"(sbase), "n"(((u) & 3) * 1024) : "memory"); \
             else                                                                                           \
@@ -314,7 +382,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         }                                                                                                  \
         _Pragma("unroll") for (int t = 0; t < NQT; ++t) {                                                  \
             const v4u b = qg[(t * KS + (u)) * 64];                                                       \
-            if (MODE == MODE_TOPK) acc[t] = CmrBlk<DT>::mma(buf[(u)], b, acc[t]); /* D[row][query] */      \
+            if (TOPK) acc[t] = CmrBlk<DT>::mma(buf[(u)], b, acc[t]); /* D[row][query] */                \
             else                   acc[t] = CmrBlk<DT>::mma(b, buf[(u)], acc[t]); /* D[query][row] */      \
         }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0); /* refill only after the slot's MFMAs were issued */            \
@@ -352,7 +420,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             gi = 0;
 
             const long long row0 = (long long)p * CMR_PANEL_ROWS;
-            if (MODE == MODE_TOPK) {
+            if (TOPK) {
                 const bool partial = row0 + CMR_PANEL_ROWS > P.nrows;
 #pragma unroll
                 for (int t = 0; t < NQT; ++t) {
@@ -372,9 +440,102 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                     }
                     rmax[t] = fmaxf(rmax[t], mx);
                     rmin[t] = fminf(rmin[t], mn);
+                    if constexpr (FIN) {
+                        // no threshold yet (tau_key 0; padding queries ~0): the whole panel goes to the lists — 16 plain stores per
+                        // lane at slots that follow from the list length, instead of 16 dependent LDS-atomic + store pairs
+                        int c0 = 0;
+                        const int ql = lane & 31;
+                        const bool valid_q = ql < nq_g;
+                        if (valid_q) c0 = __hip_atomic_load(&cnt_w[ql], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        // (the lists' invariant — at most CAP - 32 keys in front of a push — holds afterwards too; a panel that
+                        // ends the corpus or holds a NaN score takes the general path: no empty keys inside a list)
+                        bool nan = false;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) nan |= acc[0][r] != acc[0][r];
+                        if (fin_phase < 2 && !partial && !__any(valid_q && (tau_key[0] != 0ull || c0 > CAP - 64 || nan))) {
+                            if (valid_q) {
+                                u64* dst = list_w + (size_t)ql * CAP + c0 + 16 * (lane >> 5);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) dst[r] = cmr_make_key(acc[0][r], (unsigned)(row0 + cmr_acc_row(r, lane)));
+                                if (lane < 32) __hip_atomic_store(&cnt_w[ql], c0 + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            continue;
+                        }
+                    }
                     if (__any(mx >= tau_f[t]))
                         topk_slow_path<CAP>(acc[t], row0, P.nrows, P.k, tau_key[t], tau_f[t], cnt_w + t * 32,
                                             list_w + (size_t)t * 32 * CAP, stage, lane);
+                }
+                if constexpr (FIN) {
+                    // Finishing stage, part 1 — thresholds without a sampling launch.  Every wave starts with no threshold (its
+                    // first panel goes to the lists whole).  The waves of the fin_wgs workgroups that were dispatched first publish
+                    // the per-query maximum of their first panel (slot = workgroup x 8 + wave); the wave that completes the last
+                    // of those workgroups takes the k-th largest of the 8 x fin_wgs maxima per query — k distinct rows at or above
+                    // it: a valid lower bound of the global k-th best, as tight as a sample of that many panels — and publishes
+                    // it.  Nobody waits: a wave looks for the published thresholds at the end of each later panel (normally its
+                    // second) and scans on without them until then; what it pushed too generously is dropped when its list is
+                    // handed over (part 2).  All of it through device-scope loads / stores of the words concerned (write-through,
+                    // cache-bypassing) and counters on lines of their own: a release / acquire FENCE writes back / invalidates the
+                    // XCD's whole L2, and 4000 waves doing that — or 9000 atomics on one line — cost more than the launches saved
+                    // (measured: 2 M rows, one query, 741 us against 471).
+                    // (lane ids opaque in here: the per-lane addresses below would otherwise be hoisted out of the panel loop and
+                    // held — or spilled — across it)
+                    int lane_o = lane;
+                    asm volatile("" : "+v"(lane_o));
+                    if (fin_phase == 0) {
+                        if ((int)blockIdx.x < P.fin_wgs) {
+                            u64 best = 0ull;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const long long row = row0 + cmr_acc_row(r, lane_o);
+                                const float v = acc[0][r];
+                                const u64 key = cmr_make_key(v, (unsigned)row);
+                                if (row < P.nrows && v == v && key > best) best = key;
+                            }
+                            const u64 other = __shfl_xor(best, 32);
+                            best = other > best ? other : best;
+                            const int ns = P.fin_wgs * CMR_SCAN_WAVES;
+                            if (lane_o < nq_g)
+                                __hip_atomic_store(&P.fin_pmax[(size_t)lane_o * ns + (int)blockIdx.x * CMR_SCAN_WAVES + wave], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // written through before this wave is counted
+                            int o = 0;
+                            if (lane_o == 0) o = atomicAdd(&fin_sh[2], 1);
+                            o = __builtin_amdgcn_readfirstlane(o);
+                            if (o == CMR_SCAN_WAVES - 1) {                            // the workgroup's last wave: one device atomic per workgroup
+                                int dn = 0;
+                                if (lane_o == 0) dn = atomicAdd(&P.fin[CMR_FIN_DONE], 1);
+                                dn = __builtin_amdgcn_readfirstlane(dn);
+                                if (dn == P.fin_wgs - 1) {
+                                    for (int q = 0; q < nq_g; ++q) {
+                                        u64 key[16];
+#pragma unroll
+                                        for (int j = 0; j < 16; ++j) {
+                                            const int i = lane_o + 64 * j;
+                                            key[j] = i < ns ? __hip_atomic_load(&P.fin_pmax[(size_t)q * ns + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                                        }
+                                        const int kk = P.k;
+                                        u64* gt = P.fin_tau + q;
+                                        tiny_select(key, kk, stage, lane_o, [&](int r, u64 kv) {
+                                            if (r == kk - 1) __hip_atomic_store(gt, kv ? kv - 1 : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        });
+                                    }
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    if (lane_o == 0) __hip_atomic_store(&P.fin[CMR_FIN_READY], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                        }
+                        fin_phase = 1;
+                    } else if (fin_phase == 1) {
+                        if (__hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            const int q = lane_o & 31;
+                            const u64 gt = q < nq_g ? __hip_atomic_load(&P.fin_tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                            if (q < nq_g && gt > tau_key[0]) { tau_key[0] = gt; tau_f[0] = cmr_key_score(gt); }
+                            fin_phase = 2;
+#ifdef CMR_FIN_DEBUG
+                            if (lane_o == 0) { atomicAdd(&P.fin[CMR_FIN_DBG], 1); atomicAdd(&P.fin[CMR_FIN_DBG + 1], p - p0); }
+#endif
+                        }
+                    }
                 }
             } else {
                 const long long row = row0 + (lane & 31);
@@ -394,9 +555,22 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
             ++p;
         }
+        if constexpr (FIN && ASMRING) {
+            // The ring prefetched R blocks past the end of the range and hipcc knows nothing of them: the selection code behind
+            // this point reuses the ring's registers, so the loads have to land first (the statement holds every slot — nothing
+            // of the tail can be scheduled above it; build.py's audit looks for it)
+#define CMR_DRAIN_SLOT(u) v4u d##u##_ = buf[(u) < R ? (u) : 0];
+            CMR_RING_ALL(CMR_DRAIN_SLOT)
+#undef CMR_DRAIN_SLOT
+            if constexpr (R == 16)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(d0_), "+v"(d1_), "+v"(d2_), "+v"(d3_), "+v"(d4_), "+v"(d5_), "+v"(d6_), "+v"(d7_), "+v"(d8_),
+                             "+v"(d9_), "+v"(d10_), "+v"(d11_), "+v"(d12_), "+v"(d13_), "+v"(d14_), "+v"(d15_) :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(d0_), "+v"(d1_), "+v"(d2_), "+v"(d3_), "+v"(d4_), "+v"(d5_), "+v"(d6_), "+v"(d7_) :: "memory");
+        }
     }
 
-    if constexpr (MODE == MODE_TOPK) {
+    if constexpr (TOPK) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #pragma unroll
         for (int t = 0; t < NQT; ++t) {
@@ -405,15 +579,137 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             if (lane < 32) {
                 const int q = t * 32 + lane;
                 P.mm[gwl * NQ + q] = make_float2(mn, mx);
+                if constexpr (FIN) fin_mmw[wave * 32 + q] = make_float2(mn, mx);      // (reduced per workgroup in part 2)
                 P.cnt[gwl * NQ + q] = __hip_atomic_load(&cnt_w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+        }
+    }
+    if constexpr (FIN) {
+        // Finishing stage, part 2 — the final selection without a merge launch.  Every wave stages the keys of its lists that beat
+        // its FINAL threshold (any threshold a wave holds is a valid lower bound of the global k-th best: nothing that can win is
+        // dropped) in its LDS scratch; the workgroup appends them to one dense list per query with ONE device atomic per query,
+        // and the last workgroup to arrive (ticket from a counter that re-arms itself) selects the k best per query, one wave
+        // per query, and reduces the waves' min / max.  Words that cross workgroups inside the launch travel by device-scope
+        // stores / loads (see part 1).  A dense list or a staging area that overflows (thresholds that came late or loose)
+        // leaves state 2: the merge launch behind this kernel then works from the per-wave lists as ever — on state 1 it
+        // returns at once.
+        constexpr int STAGE_KEYS = 128;                      // of the wave's CAP + 2 scratch keys
+        int off = 0;
+        for (int q = 0; q < nq_g; ++q) {
+            int c = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnt_w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            c = c < CAP ? c : CAP;
+            int kept = 0;
+            if (c > 0) {
+                const u64 tq = tiny_readlane(tau_key[0], q);
+                const u64* L = list_w + (size_t)q * CAP;
+                for (int i0 = 0; i0 < c; i0 += 64) {
+                    const int i = i0 + lane;
+                    const u64 key = i < c ? L[i] : 0ull;
+                    const bool keep = key > tq;           // tq is a key - 1 or 0; empty slots are 0
+                    const u64 m = __ballot(keep);
+                    const int slot = off + kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (keep && slot < STAGE_KEYS) stage[slot] = key;
+                    kept += __popcll(m);
+                }
+            }
+            if (lane == 0) __hip_atomic_store(&cnt_w[q], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (the list length went to P.cnt above)
+            off += kept;
+        }
+        if (off > STAGE_KEYS && lane == 0) fin_sh[1] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int q = wave; q < nq_g; q += CMR_SCAN_WAVES) {
+            int total = 0;
+            float wmn = __builtin_inff(), wmx = -__builtin_inff();
+            for (int w2 = 0; w2 < CMR_SCAN_WAVES; ++w2) {
+                total += cnt_all[w2 * NQ + q];
+                const float2 v = fin_mmw[w2 * 32 + q];
+                wmn = fminf(wmn, v.x); wmx = fmaxf(wmx, v.y);
+            }
+            if (lane == 0)
+                __hip_atomic_store(&P.fin_mm[(size_t)q * gridDim.x + blockIdx.x], ((u64)__float_as_uint(wmx) << 32) | (u64)__float_as_uint(wmn),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (total == 0) continue;
+            int run = 0;
+            if (lane == 0) run = atomicAdd(&P.fin[CMR_FIN_DCNT(q)], total);
+            run = __builtin_amdgcn_readfirstlane(run);
+            for (int w2 = 0; w2 < CMR_SCAN_WAVES; ++w2) {
+                const int n = cnt_all[w2 * NQ + q];
+                if (n == 0) continue;
+                int o = 0;
+                for (int q2 = 0; q2 < q; ++q2) o += cnt_all[w2 * NQ + q2];
+                const u64* src = stage_all + (size_t)w2 * (CAP + 2) + o;
+                for (int i = lane; i < n; i += 64)
+                    if (o + i < STAGE_KEYS && run + i < P.fin_dcap)
+                        __hip_atomic_store(&P.fin_dense[(size_t)q * P.fin_dcap + run + i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run += n;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // min / max and dense keys are written through before the ticket
+        __syncthreads();
+        if (tid == 0) {
+            if (fin_sh[1]) __hip_atomic_store(&P.fin[CMR_FIN_OVER], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fin_sh[0] = atomicAdd(&P.fin[CMR_FIN_WGS], 1);
+        }
+        __syncthreads();
+        if (fin_sh[0] != (int)gridDim.x - 1) return;
+        u64* carry = reinterpret_cast<u64*>(smem) + wave * 64;      // the query tile is no longer needed
+        bool over = __hip_atomic_load(&P.fin[CMR_FIN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        for (int q = wave; q < nq_g; q += CMR_SCAN_WAVES) {
+            const int total = __hip_atomic_load(&P.fin[CMR_FIN_DCNT(q)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (total > P.fin_dcap) { over = true; continue; }
+            const u64* D = P.fin_dense + (size_t)q * P.fin_dcap;
+            const int kk = P.k;
+            int64_t* oi = P.out_ids + (size_t)q * kk;
+            float* os = P.out_scores + (size_t)q * kk;
+            const long long idb = P.id_base;
+            tiny_select_stream(total, kk, stage, carry, lane,
+                               [&](int i) -> u64 { return i < total ? __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; },
+                               [&](int r, u64 kv) {
+                                   oi[r] = kv ? (int64_t)cmr_key_row(kv) + idb : -1;
+                                   os[r] = kv ? cmr_key_score(kv) : -__builtin_inff();
+                               });
+            if (P.out_min || P.out_max) {
+                // one value per workgroup (<= 512: eight independent loads per lane — a dependent loop over the W per-wave values
+                // costs a memory round trip per iteration, 61 of them at W = 3912)
+                float mn = __builtin_inff(), mx = -__builtin_inff();
+                u64 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int b = lane + 64 * j;
+                    v[j] = b < (int)gridDim.x ? __hip_atomic_load(&P.fin_mm[(size_t)q * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : (((u64)0xFF800000u << 32) | 0x7F800000u);      // (-inf, +inf)
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { mn = fminf(mn, __uint_as_float((unsigned)v[j])); mx = fmaxf(mx, __uint_as_float((unsigned)(v[j] >> 32))); }
+#pragma unroll
+                for (int off2 = 32; off2 > 0; off2 >>= 1) { mn = fminf(mn, __shfl_xor(mn, off2)); mx = fmaxf(mx, __shfl_xor(mx, off2)); }
+                if (lane == 0) { if (P.out_min) P.out_min[q] = mn; if (P.out_max) P.out_max[q] = mx; }
+            }
+        }
+        if (over && lane == 0) fin_sh[1] = 2;
+        __syncthreads();
+#ifdef CMR_FIN_DEBUG
+        if (tid == 0) {
+            printf("FIN grid %d W %d wgs %d mul %d: done %d ready %d | adoptions %d, panels before adoption (sum) %d | dense[0] %d tau0 %f over %d\n",
+                   (int)gridDim.x, W, P.fin_wgs, P.fin_mul, P.fin[CMR_FIN_DONE], P.fin[CMR_FIN_READY], P.fin[CMR_FIN_DBG], P.fin[CMR_FIN_DBG + 1],
+                   P.fin[CMR_FIN_DCNT(0)], cmr_key_score(P.fin_tau[0]), fin_sh[1]);
+            P.fin[CMR_FIN_DBG] = 0; P.fin[CMR_FIN_DBG + 1] = 0;
+        }
+#endif
+        if (tid < 32) P.fin[CMR_FIN_DCNT(tid)] = 0;
+        if (tid == 0) {
+            P.fin[CMR_FIN_STATE] = fin_sh[1] == 2 ? 2 : 1;
+            P.fin[CMR_FIN_DONE] = 0; P.fin[CMR_FIN_READY] = 0; P.fin[CMR_FIN_WGS] = 0; P.fin[CMR_FIN_OVER] = 0;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ host
 static size_t scan_lds_bytes(int nqt, int ks, int cap) {
-    return (size_t)nqt * ks * 1024 + (size_t)CMR_SCAN_WAVES * nqt * 32 * 4 + (size_t)CMR_SCAN_WAVES * (cap + 2) * 8;
+    return (size_t)nqt * ks * 1024 + (size_t)CMR_SCAN_WAVES * nqt * 32 * 4 + (size_t)CMR_SCAN_WAVES * (cap + 2) * 8 + 16;
 }
 static constexpr size_t kLdsLimit = 160 * 1024;
 
@@ -461,6 +757,8 @@ static hipError_t dispatch(const CmrScanGeom& g, const ScanP& p, hipStream_t s) 
     if constexpr (MODE == MODE_TOPK) {
         CASE(1, 128, 8) CASE(1, 128, 16) CASE(1, 256, 8) CASE(1, 256, 16)
         CASE(2, 128, 8) CASE(2, 128, 16) CASE(2, 256, 8) CASE(2, 256, 16)
+    } else if constexpr (MODE == MODE_FIN) {
+        CASE(1, 128, 8) CASE(1, 128, 16) CASE(1, 256, 8) CASE(1, 256, 16)
     } else {
         CASE(1, 128, 8) CASE(1, 128, 16)
         CASE(2, 128, 8) CASE(2, 128, 16)
@@ -479,6 +777,9 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.sample_waves = a.sample_waves; p.sample_stride = a.sample_stride; p.sample_chunk_log2 = a.sample_chunk_log2; p.tau_init = a.tau_init;
     p.slists = a.sample_lists; p.scnt = a.sample_cnt; p.sW = a.sample_W;
     p.qgroups = a.qgroups > 1 ? a.qgroups : 1;
+    p.fin_mm = a.fin_mm;
+    p.fin = a.fin; p.fin_pmax = a.fin_pmax; p.fin_tau = a.fin_tau; p.fin_dense = a.fin_dense; p.fin_wgs = a.fin_wgs; p.fin_mul = a.fin_mul; p.fin_dcap = a.fin_dcap; p.fin_spin = a.fin_spin;
+    p.out_ids = a.out_ids; p.out_scores = a.out_scores; p.out_min = a.out_min; p.out_max = a.out_max; p.id_base = a.id_base;
     return p;
 }
 
@@ -1197,6 +1498,23 @@ hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipS
         case CMR_DT_BF16: return dispatch<CMR_DT_BF16, MODE_TOPK>(g, p, s);
         case CMR_DT_F16: return dispatch<CMR_DT_F16, MODE_TOPK>(g, p, s);
         case CMR_DT_F32: return dispatch<CMR_DT_F32, MODE_TOPK>(g, p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// top-k scan with thresholds and final selection inside the launch (MODE_FIN: one query tile, <= fin_ns <= 1024 first-panel slots)
+hipError_t cmr_launch_scan_fin(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
+    if (g.nqt != 1 || a.qgroups > 1 || !a.fin || !a.fin_pmax || !a.fin_tau || !a.fin_dense || a.fin_wgs < 1 || a.fin_wgs * CMR_SCAN_WAVES > CMR_FIN_SLOTS ||
+        a.fin_wgs > g.grid || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || a.k > 64 || a.nq > 32 || !a.out_ids || !a.out_scores || a.sample_waves > 0)
+        return hipErrorInvalidValue;
+    const ScanP p = to_p(g, a);
+    CmrScanGeom gf = g;
+    gf.lds += CMR_FIN_LDS;
+    if (gf.lds > kLdsLimit) return hipErrorInvalidValue;
+    switch (g.dtype) {
+        case CMR_DT_BF16: return dispatch<CMR_DT_BF16, MODE_FIN>(gf, p, s);
+        case CMR_DT_F16: return dispatch<CMR_DT_F16, MODE_FIN>(gf, p, s);
+        case CMR_DT_F32: return dispatch<CMR_DT_F32, MODE_FIN>(gf, p, s);
     }
     return hipErrorInvalidValue;
 }
