@@ -93,14 +93,69 @@ def _ring_loop_membership(body: list, ring_line: int) -> list:
     return [inside(b) for b in block_of]
 
 
+_BRANCH_RE = re.compile(r"^(s_branch|s_cbranch_\w+)\s+\.L(BB\d+_\d+)")
+_DRAIN_RE = re.compile(r"^s_waitcnt\s+vmcnt\(0\)")
+
+
+def _ring_in_flight(body: list, in_loop: list) -> list:
+    """Per line: may a load of the asm ring still be in flight there?  Inside the ring loop always (the previous iteration's
+    loads).  Outside: on every path that LEAVES the loop, up to the first `s_waitcnt vmcnt(0)` (the compiler's or the kernel's own
+    drain statement) — found by walking the control flow (labels, s_branch / s_cbranch, fall-through); code that only runs in
+    front of the loop (wherever LLVM placed it in the text) is not reached and may set the registers up."""
+    label_at = {}
+    for n, l in enumerate(body):
+        m = re.match(r"^\.L(BB\d+_\d+):", l.strip())
+        if m:
+            label_at[m.group(1)] = n
+    hot = list(in_loop)
+    work = []
+
+    def targets(n):       # (branch targets, falls through?)
+        code = body[n].strip().split(";")[0].strip()
+        m = _BRANCH_RE.match(code)
+        if m:
+            return [label_at.get(m.group(2))], m.group(1) != "s_branch"
+        if code.startswith("s_endpgm"):
+            return [], False
+        return [], True
+
+    for n in range(len(body)):
+        if not in_loop[n]:
+            continue
+        tg, fall = targets(n)
+        for t in tg:
+            if t is not None and not in_loop[t]:
+                work.append(t)
+        if fall and n + 1 < len(body) and not in_loop[n + 1]:
+            work.append(n + 1)
+    seen = set()
+    while work:
+        n = work.pop()
+        while n < len(body) and n not in seen and not in_loop[n]:
+            seen.add(n)
+            code = body[n].strip()
+            if _DRAIN_RE.match(code.split(";")[0].strip()):      # (asm statements included: their text is the instruction)
+                break
+            hot[n] = True
+            tg, fall = targets(n)
+            for t in tg:
+                if t is not None and t not in seen and not in_loop[t]:
+                    work.append(t)
+            if not fall:
+                break
+            n += 1
+    return hot
+
+
 def audit_ring(asm_text: str) -> dict:
     """For every scan_kernel<..., ASMRING=1> in the gfx950 assembly decide whether the hand-counted
     load ring is safe: the ring's VGPRs (destinations of the global_load_dwordx4 inside
     ;;#ASMSTART/;;#ASMEND) may be written only by that asm and read only by v_mfma; any other
     compiler instruction touching them after the first ring load (a copy, a spill, a reuse)
-    could observe a slot before its data landed (cdna guide §5.7 item 1).  Code that is outside the ring
-    loop AND behind a compiler `s_waitcnt vmcnt(0)` that follows the loop (the fence in front of the kernel's tail) may reuse
-    them: nothing is in flight there.  Also requires zero scratch.  Returns {(dt,nqt,cap,ring,mode): bool}."""
+    could observe a slot before its data landed (cdna guide §5.7 item 1).  "In flight" is decided on the control flow
+    (`_ring_in_flight`): everywhere inside the ring loop, and on the paths that leave it up to the first `s_waitcnt vmcnt(0)`;
+    code in front of the loop and behind such a drain may use the registers.  Also requires zero scratch.
+    Returns {(dt,nqt,cap,ring,mode): bool}."""
     result = {}
     lines = asm_text.split("\n")
     i = 0
@@ -132,9 +187,8 @@ def audit_ring(asm_text: str) -> dict:
                 last_ring_load = n
         ok = len(ring_regs) == 4 * ring
         in_ring_loop = _ring_loop_membership(body, last_ring_load)
-        loaded: set = set()   # ring registers that already received an asm load
+        hot = _ring_in_flight(body, in_ring_loop)      # lines at which a ring load may still be in flight
         in_asm = False
-        drained = False       # behind the ring loop AND behind a compiler s_waitcnt vmcnt(0): no ring load is in flight any more
         for n, l in enumerate(body):
             s = l.strip()
             if not s or (s.startswith(";") and not s.startswith(";;#ASM")):
@@ -146,21 +200,11 @@ def audit_ring(asm_text: str) -> dict:
                 in_asm = False
                 continue
             if in_asm:
-                if s.startswith("global_load_dwordx4"):
-                    loaded |= _regs(s.split(",")[0])
-                elif n > last_ring_load and not in_ring_loop[n] and re.match(r"s_waitcnt\s+vmcnt\(0\)", s):
-                    drained = True      # the kernel's own drain statement behind the loop (it holds every ring slot)
                 continue
             if "scratch_" in s:
                 ok = False
             code = s.split(";")[0]
-            if n > last_ring_load and not in_ring_loop[n] and re.match(r"s_waitcnt\s+vmcnt\(0\)", code):
-                drained = True
-            if drained and not in_ring_loop[n]:
-                continue          # code behind the loop (the finishing stage's selection) may reuse the registers
-            # inside the ring loop every ring register is in flight at every point (the loads of the previous iteration): the
-            # textual order says nothing there; in front of / behind the loop it does
-            if _regs(code) & (ring_regs if in_ring_loop[n] else loaded):
+            if hot[n] and _regs(code) & ring_regs:
                 if code.startswith("v_mfma"):
                     if _regs(code.split(",")[0]) & ring_regs:
                         ok = False

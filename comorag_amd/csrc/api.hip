@@ -180,11 +180,12 @@ struct cmr_index {
     int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
     int scan_fin = 1;        // scan_fin = 0: small synchronous batches on corpora beyond the single-launch path run the sampling / scan / merge chain
                              // instead of the scan with the finishing stage (thresholds and final selection inside the scan launch)
-    int fin_dense = 4096;    // scan_fin_dense: keys per query of the finishing stage's dense candidate lists (~k x panels / 1024 beat a threshold taken
+    int fin_dense = 16384;   // scan_fin_dense: keys per query of the finishing stage's dense candidate lists (~k x panels / 1024 beat a threshold taken
                              // from 1024 first panels: 600 at 1 M rows, 6 K at 10 M; a list that overflows hands the selection to the merge launch)
     int fin_spin = 0;        // scan_fin_spin: rounds of ~1.5 us the workgroups that do not supply thresholds wait for them before they scan without (0: they look once)
-    int fin_max_q = 4;       // scan_fin_queries: largest batch the finishing stage takes (<= 32; one wave derives the thresholds query by query: measured at 768-d bf16,
-                             // 1 M rows — 1 / 2 / 4 queries 270 / 284 / 301 us against 302 / 315 / 337 for the chain, 8 queries 362 against 338)
+    int fin_max_q = 8;       // scan_fin_queries: largest batch the finishing stage takes (<= 16).  Measured at 768-d bf16, per call, stage / chain:
+                             // 1 M rows — 1 / 2 / 4 / 8 / 16 queries 287 / 292 / 297 / 322 / 392 us against 300 / 313 / 333 / 336 / 372;
+                             // 2 M rows — 520 / 523 / 525 / 538 / 589 against 563 / 560 / 577 / 588 / 615
     int dual_wide_active = 0;   // read-only ("pipe_dual_scan_wide_active"): the same for the last wide pass
     int dual_active = 0;     // read-only ("pipe_dual_scan_active"): did the last pipelined <= 64-query pass alternate between the two scan streams
     long long id_base = 0;   // added to every returned row id (global ids of a row shard)
@@ -226,7 +227,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "scan_fin") idx->scan_fin = (int)v;
     else if (n == "scan_fin_dense") idx->fin_dense = (int)std::max<long long>(1, std::min<long long>(v, 1 << 16));
     else if (n == "scan_fin_spin") idx->fin_spin = (int)std::max<long long>(0, std::min<long long>(v, 1000));
-    else if (n == "scan_fin_queries") idx->fin_max_q = (int)std::max<long long>(1, std::min<long long>(v, 32));
+    else if (n == "scan_fin_queries") idx->fin_max_q = (int)std::max<long long>(1, std::min<long long>(v, CMR_FIN_MAX_QUERIES));
     else if (n == "sample_div") idx->sample_div = (int)std::max<long long>(2, v);
     else if (n == "sample_maxmul") idx->sample_maxmul = (int)std::max<long long>(0, v);
     else if (n == "pipe_reserve_cus") idx->reserve_cus = (int)v;

@@ -74,13 +74,15 @@ struct CmrScanArgs {
 };
 // control words (ints) — every counter on a 128-byte line of its own: device atomics on one line serialise
 #define CMR_FIN_DONE 0        // workgroups whose waves have all published their first-panel maxima
-#define CMR_FIN_READY 32      // thresholds published
+#define CMR_FIN_READY 32      // bit q: the threshold of query q is published; bit 31: every first-panel maximum is
 #define CMR_FIN_WGS 64        // workgroups finished
 #define CMR_FIN_STATE 96      // result state: 1 = the scan wrote the final results itself, 2 = a list overflowed (the merge launch decides)
 #define CMR_FIN_OVER 128      // some workgroup's staging area overflowed
 #define CMR_FIN_DBG 136
-#define CMR_FIN_DCNT(q) (160 + 32 * (q))     // dense list lengths
-#define CMR_FIN_CTL (160 + 32 * 32)
+#define CMR_FIN_CLAIM 192     // queries whose threshold somebody has taken on
+#define CMR_FIN_MAX_QUERIES 16
+#define CMR_FIN_DCNT(q) (224 + 32 * (q))     // dense list lengths
+#define CMR_FIN_CTL (224 + 32 * 32)
 #define CMR_FIN_LDS 2048      // bytes of LDS the finishing stage adds to the geometry's (the waves' min / max)
 #define CMR_FIN_SLOTS 1024    // first-panel maxima the thresholds are taken from (one selection chunk of a wave)
 

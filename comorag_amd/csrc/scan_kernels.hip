@@ -173,6 +173,23 @@ __device__ __forceinline__ void topk_slow_path(const f32x16& acc, long long row0
     if (need) topk_compact<CAP>(need, k, tau_key, tau_f, cnt_t, list_t, stage, lane);
 }
 
+// MODE_FIN: the threshold of query q from the published first-panel maxima of the ns supplying waves (one selection chunk:
+// <= 1024 keys, 16 per lane) — the k-th largest of them, written through before the query's bit in `ready` says so
+__device__ __forceinline__ void fin_threshold(const u64* pmax, int ns, int k, u64* tau, int* ready, u64* stage, int q, int lane) {
+    u64 key[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        key[j] = i < ns ? __hip_atomic_load(&pmax[(size_t)q * ns + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    u64* gt = tau + q;
+    tiny_select(key, k, stage, lane, [&](int r, u64 kv) {
+        if (r == k - 1) __hip_atomic_store(gt, kv ? kv - 1 : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) atomicOr(ready, 1 << q);
+}
+
 template <int DT, int NQT, int CAP, int R, int MODE, int ASMRING, int POL = 1>
 __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     // FIN: the workgroups that are dispatched first supply the thresholds (their first panels); a multiplicative permutation of the
     // workgroup ids spreads their panel ranges over the whole corpus (rows arrive document by document: a sample of one region
     // would be valid but loose)
-    if constexpr (FIN) bid = (int)(((long long)bid * P.fin_mul) % (long long)gridDim.x);
+    if constexpr (FIN) bid = __builtin_amdgcn_readfirstlane((int)(((unsigned)bid * (unsigned)P.fin_mul) % gridDim.x));     // (the division runs on the VALU: say that it is uniform)
     const int nq_g = P.nq - grp * NQ;          // queries of this group (the last group may be ragged)
     {
         const v4u* qsrc = P.qfrag + (size_t)grp * NQT * KS * 64;
@@ -311,7 +328,8 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             if (wave == 0) {
                 int rdy = 0;
                 for (int spin = 0;; ++spin) {
-                    rdy = __hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int full = (int)((1u << nq_g) - 1u);
+                    rdy = (__hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & full) == full;
                     if (rdy || spin >= P.fin_spin) break;
                     __builtin_amdgcn_s_sleep(48);
                 }
@@ -506,27 +524,24 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                                 if (lane_o == 0) dn = atomicAdd(&P.fin[CMR_FIN_DONE], 1);
                                 dn = __builtin_amdgcn_readfirstlane(dn);
                                 if (dn == P.fin_wgs - 1) {
-                                    for (int q = 0; q < nq_g; ++q) {
-                                        u64 key[16];
-#pragma unroll
-                                        for (int j = 0; j < 16; ++j) {
-                                            const int i = lane_o + 64 * j;
-                                            key[j] = i < ns ? __hip_atomic_load(&P.fin_pmax[(size_t)q * ns + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                                        }
-                                        const int kk = P.k;
-                                        u64* gt = P.fin_tau + q;
-                                        tiny_select(key, kk, stage, lane_o, [&](int r, u64 kv) {
-                                            if (r == kk - 1) __hip_atomic_store(gt, kv ? kv - 1 : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        });
+                                    // every maximum is published: bit 31 says so, and the thresholds are taken query by query by
+                                    // whoever claims one — this wave, and every wave that comes past a panel end meanwhile
+                                    if (lane_o == 0) atomicOr(&P.fin[CMR_FIN_READY], (int)0x80000000u);
+                                    // (a counted loop, every lane in the atomic: whatever the compiler makes of it, it ends)
+                                    for (int it = 0; it < nq_g; ++it) {
+                                        int cq = __hip_atomic_fetch_add(&P.fin[CMR_FIN_CLAIM], lane_o == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        cq = __builtin_amdgcn_readfirstlane(cq);
+                                        if (cq < nq_g)
+                                            fin_threshold(P.fin_pmax, P.fin_wgs * CMR_SCAN_WAVES, P.k, P.fin_tau, &P.fin[CMR_FIN_READY], stage, cq, lane_o);
                                     }
-                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                    if (lane_o == 0) __hip_atomic_store(&P.fin[CMR_FIN_READY], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 }
                             }
                         }
                         fin_phase = 1;
                     } else if (fin_phase == 1) {
-                        if (__hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        const int rd = __hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int full = (int)((1u << nq_g) - 1u);
+                        if ((rd & full) == full) {
                             const int q = lane_o & 31;
                             const u64 gt = q < nq_g ? __hip_atomic_load(&P.fin_tau[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                             if (q < nq_g && gt > tau_key[0]) { tau_key[0] = gt; tau_f[0] = cmr_key_score(gt); }
@@ -534,6 +549,10 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
 #ifdef CMR_FIN_DEBUG
                             if (lane_o == 0) { atomicAdd(&P.fin[CMR_FIN_DBG], 1); atomicAdd(&P.fin[CMR_FIN_DBG + 1], p - p0); }
 #endif
+                        } else if (rd < 0) {                      // published, thresholds incomplete: take one
+                            int cq = __hip_atomic_fetch_add(&P.fin[CMR_FIN_CLAIM], lane_o == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            cq = __builtin_amdgcn_readfirstlane(cq);
+                            if (cq < nq_g) fin_threshold(P.fin_pmax, P.fin_wgs * CMR_SCAN_WAVES, P.k, P.fin_tau, &P.fin[CMR_FIN_READY], stage, cq, lane_o);
                         }
                     }
                 }
@@ -594,26 +613,40 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         // leaves state 2: the merge launch behind this kernel then works from the per-wave lists as ever — on state 1 it
         // returns at once.
         constexpr int STAGE_KEYS = 128;                      // of the wave's CAP + 2 scratch keys
+        constexpr int EPL = CAP / 64;
         int off = 0;
-        for (int q = 0; q < nq_g; ++q) {
-            int c = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnt_w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            c = c < CAP ? c : CAP;
-            int kept = 0;
-            if (c > 0) {
-                const u64 tq = tiny_readlane(tau_key[0], q);
-                const u64* L = list_w + (size_t)q * CAP;
-                for (int i0 = 0; i0 < c; i0 += 64) {
-                    const int i = i0 + lane;
-                    const u64 key = i < c ? L[i] : 0ull;
-                    const bool keep = key > tq;           // tq is a key - 1 or 0; empty slots are 0
-                    const u64 m = __ballot(keep);
-                    const int slot = off + kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (keep && slot < STAGE_KEYS) stage[slot] = key;
-                    kept += __popcll(m);
+        for (int q0 = 0; q0 < nq_g; q0 += 8) {                // eight lists at a time: one memory round trip, not eight
+            u64 lk[8][EPL];
+            int lc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j;
+                int c = 0;
+                if (q < nq_g) c = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnt_w[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                lc[j] = c < CAP ? c : CAP;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const int i = lane + 64 * e;
+                    lk[j][e] = i < lc[j] ? list_w[(size_t)q * CAP + i] : 0ull;
                 }
             }
-            if (lane == 0) __hip_atomic_store(&cnt_w[q], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (the list length went to P.cnt above)
-            off += kept;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = q0 + j;
+                if (q >= nq_g) break;
+                const u64 tq = tiny_readlane(tau_key[0], q);
+                int kept = 0;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const bool keep = lk[j][e] > tq;          // tq is a key - 1 or 0; empty slots are 0
+                    const u64 m = __ballot(keep);
+                    const int slot = off + kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if (keep && slot < STAGE_KEYS) stage[slot] = lk[j][e];
+                    kept += __popcll(m);
+                }
+                if (lane == 0) __hip_atomic_store(&cnt_w[q], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // (the list length went to P.cnt above)
+                off += kept;
+            }
         }
         if (off > STAGE_KEYS && lane == 0) fin_sh[1] = 1;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -702,7 +735,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         if (tid < 32) P.fin[CMR_FIN_DCNT(tid)] = 0;
         if (tid == 0) {
             P.fin[CMR_FIN_STATE] = fin_sh[1] == 2 ? 2 : 1;
-            P.fin[CMR_FIN_DONE] = 0; P.fin[CMR_FIN_READY] = 0; P.fin[CMR_FIN_WGS] = 0; P.fin[CMR_FIN_OVER] = 0;
+            P.fin[CMR_FIN_DONE] = 0; P.fin[CMR_FIN_READY] = 0; P.fin[CMR_FIN_WGS] = 0; P.fin[CMR_FIN_OVER] = 0; P.fin[CMR_FIN_CLAIM] = 0;
         }
     }
 }
@@ -1505,7 +1538,7 @@ hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipS
 // top-k scan with thresholds and final selection inside the launch (MODE_FIN: one query tile, <= fin_ns <= 1024 first-panel slots)
 hipError_t cmr_launch_scan_fin(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
     if (g.nqt != 1 || a.qgroups > 1 || !a.fin || !a.fin_pmax || !a.fin_tau || !a.fin_dense || a.fin_wgs < 1 || a.fin_wgs * CMR_SCAN_WAVES > CMR_FIN_SLOTS ||
-        a.fin_wgs > g.grid || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || a.k > 64 || a.nq > 32 || !a.out_ids || !a.out_scores || a.sample_waves > 0)
+        a.fin_wgs > g.grid || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || a.k > 64 || a.nq > CMR_FIN_MAX_QUERIES || !a.out_ids || !a.out_scores || a.sample_waves > 0)
         return hipErrorInvalidValue;
     const ScanP p = to_p(g, a);
     CmrScanGeom gf = g;
