@@ -638,7 +638,9 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                 int kept = 0;
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
-                    const bool keep = lk[j][e] > tq;          // tq is a key - 1 or 0; empty slots are 0
+                    // >=, not >: a threshold raised by a compaction of this very list IS its k-th best key (the published ones are
+                    // a key - 1); empty slots are 0
+                    const bool keep = lk[j][e] != 0ull && lk[j][e] >= tq;
                     const u64 m = __ballot(keep);
                     const int slot = off + kept + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                     if (keep && slot < STAGE_KEYS) stage[slot] = lk[j][e];

@@ -158,3 +158,20 @@ def test_finishing_stage_on_the_callers_stream_and_through_the_multi_device_inde
     got = m.search(Q, 20)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     m.close(); one.close(); chain.close()
+
+
+def test_finishing_stage_keeps_the_key_a_compaction_made_the_threshold():
+    """k = 1 (and small k): a list compacted before the published thresholds arrive has its own k-th best AS its threshold — the
+    hand-over must keep that key.  Whether a wave compacts depends on timing: many repetitions, every one against the chain."""
+    X, Q = _mk(400_000, 64, 8, seed=31)
+    X[399_990] = Q[0]; X[17] = Q[3]; X[123_456] = Q[7]
+    fin = _index("bf16", X)
+    chain = _index("bf16", X, {"scan_fin": 0})
+    for k in (1, 2, 5):
+        want = chain.search(Q, k)
+        one = chain.search(Q[:1], k)
+        for _ in range(15):
+            assert _same(fin.search(Q, k), want)
+            assert _same(fin.search(Q[:1], k), one)
+    assert fin.search(Q[:1], 1)[0][0, 0] == 399_990
+    fin.close(); chain.close()
