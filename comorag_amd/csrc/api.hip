@@ -80,7 +80,8 @@ struct Workspace {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     DevBuf qfrag, lists, cnt, mm, flag, tau, s_lists, s_cnt, s_mm, arrive;
-    DevBuf fin_ctl, fin_pmax, fin_tau, fin_dense, fin_mm;      // scan with the finishing stage (cmr_launch_scan_fin)
+    DevBuf fin_ctl, fin_pmax, fin_tau, fin_dense, fin_mm;
+    bool fin_ctl_armed = false;      // scan with the finishing stage (cmr_launch_scan_fin)
     // host-API staging
     DevBuf d_q, d_ids, d_scores, d_min, d_max, d_cand, d_out;
     // synchronous search: queries in, (ids | scores | min | max | non-finite flag) out through ONE pinned host buffer and
@@ -624,9 +625,10 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     const int* fin_state = nullptr;
     if (fin) {
         const int kFinDenseCap = idx->fin_dense;
-        if (!ws->fin_ctl.p) {                   // zeroed once; the kernel's last workgroup re-arms the words
+        if (!ws->fin_ctl_armed) {               // zeroed once; the kernel's last workgroup re-arms the words
             HIP_TRY(ws->fin_ctl.ensure(CMR_FIN_CTL * sizeof(int)));
             HIP_TRY(hipMemsetAsync(ws->fin_ctl.p, 0, CMR_FIN_CTL * sizeof(int), sm));
+            ws->fin_ctl_armed = true;           // (only once the zeroing is in the stream: garbage counters would end in garbage results)
         }
         HIP_TRY(ws->fin_pmax.ensure((size_t)32 * CMR_FIN_SLOTS * 8));
         HIP_TRY(ws->fin_tau.ensure(32 * 8));
