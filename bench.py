@@ -821,7 +821,9 @@ def main():
                 "config2_1M_rows_qps": _get(extra, f"config2_{min(args.rows, 1_000_000)}_rows_batch{args.batch}", "value"),
                 "shard_1p25M_rows_batch256_ms_per_step": _get(extra, f"config3_one_of_8_shards_{min(args.rows, 1_250_000)}_rows_batch256", "ms_per_step"),
                 "corpus_embed_bf16_chunks_per_s": _get(extra, "corpus_embed_bf16", "value"),
-                "single_query_latency_1M_rows_us": _get(extra, "single_query_latency", "rows", str(min(args.rows, 1_000_000)))}
+                "single_query_latency_1M_rows_us": _get(extra, "single_query_latency", "rows", str(min(args.rows, 1_000_000))),
+                "config4_search_us_per_call": _get(extra, "config4_probe_loop", "search_us_per_call"),
+                "config4_call_frac_of_hbm": _get(extra, "config4_probe_loop", "frac")}
         out["config"].update({f"x_{k_}": v_ for k_, v_ in flat.items() if v_ is not None})
     left_cleanly = True
     if world > 1:
