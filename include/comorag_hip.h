@@ -157,14 +157,18 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * against each other bit for bit; tools A/B kernel decisions with them).  Nothing is read from the environment by the
  * shipped library.  Names: scan_ring (8 | 16), scan_asm_ring (0 | 1), scan_grid, scan_no_sample, scan_no_wide (batches of
  * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
- * paths), zero_copy, sample_single, sample_tau_in_scan, sample_div, sample_maxmul, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
+ * paths), zero_copy, sample_single, sample_single_max, sample_tau_in_scan, sample_div, sample_maxmul, scan_fin (0: small synchronous
+ * batches run the sampling / scan / merge chain instead of the scan with the finishing stage) / scan_fin_queries (<= 16) /
+ * scan_fin_dense / scan_fin_spin, wide_mode (1: register-resident wide kernel | 2: query-split grid of the narrow kernel),
+ * stream_nt, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
  * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0: never | 1 | 2: every scan; default: scans shorter than ~1 ms) and
  * pipe_dual_scan (0 | 1; default: scans shorter than ~1 ms) — the pipelined search's streams with explicit CU masks (scans
  * of <= 64-query batches on n_cu - 64 CUs, their pre-phases on the other 64) and two alternating scan streams; both must
  * be set before the first pipelined call.
  * Unknown names: CMR_ERR_INVALID.
  * The wide-batch kernel exists for padded dims 768 (256 queries per pass) and 1024 (128 per pass) in bf16 / f16; any other
- * dim and every fp32 index run a batch of B > 64 queries as ceil(B / 64) passes of the narrow kernel — same results.       */
+ * dim and every fp32 index run a batch of B > 64 queries on the query-split grid of the narrow kernel (up to four query tiles
+ * per corpus pass) — same results.                                                                                           */
 int32_t cmr_index_set_option(cmr_index_t* idx, const char* name, int64_t value);
 /* What the pipeline actually does (read-only): "pipe_dual_scan_active" / "pipe_dual_scan_wide_active" (the last pipelined <= 64-query / wide pass alternated between
  * the two scan streams: by default only scans shorter than ~1 ms do — launches that overlap have no per-launch duration, so a
