@@ -283,6 +283,26 @@ def test_ring_variants_agree(env):
     assert np.array_equal(a_ids, b_ids) and np.array_equal(a_sc, b_sc)
 
 
+@pytest.mark.parametrize("dtype,nq", [("bf16", 1), ("bf16", 8), ("f32", 5), ("f16", 32)])
+def test_one_tile_kernels_hand_counted_ring_equals_compiler_counted(dtype, nq):
+    """<= 32 queries run the one-tile kernels; their hand-counted load ring only exists since the accumulator rides along with the
+    reloads (LLVM sank the single MFMA of a slot below them and read the slot through a copy made before its wait).
+    General chain forced (no single-launch path, no finishing stage), both ring builds, top-k and all-scores modes."""
+    from comorag_amd.index import DenseIndex
+    X, Q = _mk(90_001, 384, nq, seed=17 + nq)
+    outs = []
+    for asm in (1, 0):
+        idx = DenseIndex(384, dtype, options={"scan_no_tiny": 1, "scan_fin": 0, "scan_asm_ring": asm, "zero_copy": 0})
+        idx.append(X)
+        outs.append((idx.search(Q, 20), idx.scores(Q)))
+        idx.close()
+    assert all(np.array_equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    rnd = ROUND[dtype]
+    exact = orc.exact_scores_f64(rnd(X), rnd(Q))
+    np.testing.assert_allclose(outs[0][1], exact, atol=ERR, rtol=0)
+
+
 def test_ties_index_ascending():
     from comorag_amd.index import DenseIndex
     X = orc.synthetic_corpus(500, 64, seed=5)
