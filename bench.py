@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="the timed K-step region is run this many times back to back (same warm state, each one bracketed by "
+                                                            "barrier + synchronize); value / ms_per_step are the MEDIAN region, min / max beside them")
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=64)
@@ -124,6 +126,13 @@ def gen_rows_dev(torch, lo, hi, dim, device, block=250_000):
             del x
 
 
+def _generator_note():
+    """Which generator drew the corpus (goes into the JSON line's `data`)."""
+    return ("numpy default_rng([1234, block]) on the host, SURVEY 8(d) literally" if SURVEY_RNG else
+            "torch device generator (torch.randn, seed 1234 * 1000003 + block per 250 K-row block), rows L2-normalised in fp32: "
+            "SURVEY 8(d)'s distribution, not its numpy bit stream (--survey-rng draws that one)")
+
+
 def build_shard(torch, args, rows, rank, world, device, host=None, timing=False):
     """host: a preallocated fp32 array [hi - lo, dim] that receives the shard's rows (for the CPU legs)."""
     from comorag_amd.sharded import ShardedIndex, shard_bounds
@@ -162,36 +171,40 @@ def make_queries(torch, n_batches, batch, dim, device, seed):
     return out
 
 
-def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFILE_EVERY, ctl="cuda"):
-    """qs: list of query batches, step i takes qs[i % len(qs)].  Returns (seconds, profile, last batch's buffers, index of
-    the query batch of the last step)."""
+def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFILE_EVERY, ctl="cuda", repeats=1):
+    """qs: list of query batches, step i takes qs[i % len(qs)].  The timed region (exactly `steps` steps between barrier +
+    synchronize on both sides, max over ranks) is run `repeats` times back to back after ONE warm-up.
+    Returns (median seconds, profile, last batch's buffers, index of the query batch of the last step, all regions' seconds)."""
     for i in range(warmup):
         sh.search_pipelined(qs[i % len(qs)], k, i & 1)["done"].synchronize()
     torch.cuda.synchronize(device)
     sh.times = []
-    sh.local.profile(every)       # HIP events around every `every`-th main scan of the timed region
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
+    sh.local.profile(every)       # HIP events around every `every`-th main scan of the timed regions
+    dts = []
     last = None
-    for i in range(steps):
-        last = sh.search_pipelined(qs[i % len(qs)], k, i & 1)
-    last["done"].synchronize()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    for _ in range(max(1, repeats)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            last = sh.search_pipelined(qs[i % len(qs)], k, i & 1)
+        last["done"].synchronize()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device if ctl == "cuda" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        dts.append(dt)
     sh.local.profile(False)
     prof = sh.local.profile_collect()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if ctl == "cuda" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     ex = sh.exchange_times_ms() if sh.timing else []
     prof["exchange_ms"] = float(np.mean([a for a, _ in ex])) if ex else 0.0
     prof["merge_ms"] = float(np.mean([m for _, m in ex])) if ex else 0.0
-    return dt, prof, last, (steps - 1) % len(qs)
+    return float(np.median(dts)), prof, last, (steps - 1) % len(qs), dts
 
 
 def verify_last_batch(sh, last, qh, k):
@@ -253,6 +266,8 @@ def cpu_baseline(args, seconds, X, Q, gpu_ids, full_size):
     ref_ids = best_i.numpy()
     recall = float(np.mean([len(set(gpu_ids[i].tolist()) & set(ref_ids[i].tolist())) / args.k for i in range(len(Q))]))
     out = {"value": qps_sample * scale, "unit": "queries/s", "cores": int(ti.get("blas_threads", 1)), "kind": "port",
+           "value_is": "SINGLE-query dense_passage_retrieval (what ComoRAG issues: np.dot + min-max + FULL argsort of all rows per query); the like-for-like "
+                       "batched top-k comparator is `batched_value` below",
            "kind_note": "oracle/retrieval_np.py, the line-by-line numpy restatement of the reference functions (pinned to reference "
                         "outputs in tests/); the reference tree itself does not exist on the GPU box",
            "sample": f"{done} single-query dense_passage_retrieval calls (np.dot + min-max + full argsort, fp32) over "
@@ -262,15 +277,32 @@ def cpu_baseline(args, seconds, X, Q, gpu_ids, full_size):
            "recall_at_k_vs_cpu_fp32": recall,
            "recall_note": f"top-{args.k} ids of the {args.dtype} HIP index from the LAST TIMED PIPELINED batch of the headline configuration "
                           f"vs the fp32 CPU ranking (torch.mm + topk), {len(Q)} queries, {n} rows"}
-    # (ii) batched CPU comparator
+    # (ii) batched CPU comparator — the like-for-like CPU leg of `value` (same batch, same k, the SAME rows: utils/embed_utils.py:8-97's
+    # torch.mm + torch.topk per 10000-key block, forced onto the CPU); its figure sits at the TOP LEVEL next to the single-query one
     try:
-        nk = min(n, 1_000_000)
+        import torch
         orc.retrieve_knn_torch_cpu(Q[:8], X[:100_000], k=args.k)
+        nk = n                  # the reference normalises a COPY of the keys: all rows only when the host has room for it
+        try:
+            import psutil
+            if psutil.virtual_memory().available < 1.5 * X.nbytes + (8 << 30):
+                nk = min(n, 1_000_000)
+        except Exception:
+            nk = min(n, 1_000_000)
         t0 = time.perf_counter(); reps = 0
-        while reps < 3 and time.perf_counter() - t0 < max(4.0, seconds / 3):
+        while reps < 3 and time.perf_counter() - t0 < max(6.0, seconds / 2):
             orc.retrieve_knn_torch_cpu(Q, X[:nk], k=args.k); reps += 1
         dtb = (time.perf_counter() - t0) / max(reps, 1)
-        out["batched_retrieve_knn"] = {"value": len(Q) / dtb, "unit": "queries/s", "batch": len(Q), "k": args.k, "keys": nk, "ms_per_batch": dtb * 1e3,
+        bt = int(torch.get_num_threads())
+        full_b, scale_b = (full_size and nk == n), args.rows / nk
+        out["batched_value"] = len(Q) / dtb / scale_b
+        out["batched_unit"] = "queries/s"
+        out["batched_cores"] = bt
+        out["batched_sample"] = (f"{reps} call(s) of retrieve_knn forced onto the CPU (utils/embed_utils.py:8-97: fp32 normalise, torch.mm + torch.topk per 10000-key "
+                                 f"block, final topk), batch {len(Q)}, k = {args.k}, over {'ALL' if full_b else 'the first'} {nk} rows of the bench corpus, "
+                                 f"{dtb * 1e3:.0f} ms per batch on {bt} torch intra-op threads of {os.cpu_count()} host CPUs"
+                                 + ("" if full_b else f"; time linearly scaled x{scale_b:g} to {args.rows} rows"))
+        out["batched_retrieve_knn"] = {"value": len(Q) / dtb / scale_b, "unit": "queries/s", "batch": len(Q), "k": args.k, "keys": nk, "ms_per_batch": dtb * 1e3, "threads": bt,
                                        "what": "utils/embed_utils.py:8-97 forced onto the CPU (fp32 normalise, torch.mm + torch.topk per 10000-key block, merge)"}
     except Exception as e:
         out["batched_retrieve_knn"] = {"error": repr(e)[:300]}
@@ -338,7 +370,7 @@ def single_query_latency(torch, args, device, sizes=(6, 1000, 10_000, 100_000)):
             "all_scores_rows": all_scores, "all_scores_note": "cmr_index_scores, one query: what dense_passage_retrieval / get_fact_scores call (median of 30)"}
 
 
-def summarise(batch, steps, dt, prof, rows_gpu, dim, dual=False):
+def summarise(batch, steps, dt, prof, rows_gpu, dim, dual=False, dts=None):
     """dual: the pass alternated between the index's two scan streams (short scans, cmr_index_get_option
     "pipe_dual_scan_active"): consecutive launches overlap — a launch's begin-to-end then includes the wait for the CUs of the
     previous scan, it is no duration — so that row's HBM figures are algorithmic bytes / STEP time (a lower bound of what the
@@ -349,6 +381,9 @@ def summarise(batch, steps, dt, prof, rows_gpu, dim, dual=False):
     out = {"value": batch * steps / dt, "unit": "queries/s", "batch": batch, "ms_per_step": step_ms,
            "hbm_GBps_step": by / (step_ms * 1e-3) / 1e9 if step_ms else 0.0, "frac_step_of_8TBps": by / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if step_ms else 0.0,
            "two_scan_streams": bool(dual), "exchange_ms": prof["exchange_ms"], "merge_ms": prof["merge_ms"]}
+    if dts and len(dts) > 1:        # the timed region was repeated: dt is the median region
+        out.update({"repeats": len(dts), "ms_per_step_all": [d / steps * 1e3 for d in dts], "ms_per_step_min": min(dts) / steps * 1e3,
+                    "ms_per_step_max": max(dts) / steps * 1e3, "value_min": batch * steps / max(dts), "value_max": batch * steps / min(dts)})
     if dual:
         out.update({"kernel_ms": None, "kernel_lifetime_ms": ms, "hbm_GBps": out["hbm_GBps_step"], "frac_of_8TBps": out["frac_step_of_8TBps"],
                     "mfma_TFLOPs": 2.0 * batch * rows_gpu * dim / (step_ms * 1e-3) / 1e12 if step_ms else 0.0,
@@ -437,7 +472,7 @@ def single_process_main(args):
 
     head, qs, last = run(args.batch, args.steps, args.warmup, 4321)
     out = {"metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (numpy default_rng([1234, block]) rows, SURVEY 8d)" if SURVEY_RNG else ""),
+           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic; corpus rows drawn by " + _generator_note(),
            "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} (north_star target config; corpus fixed, "
                                   f"row-sharded over {n} device(s) driven from ONE process)",
                       "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "process_model": f"one process, {n} shard(s) on devices {devices} (MultiDeviceIndex)",
@@ -497,7 +532,7 @@ def single_process_leg(args):
         if p.returncode != 0 or not lines:
             return {"error": f"exit code {p.returncode}", "stderr_tail": se[-600:]}
         d = json.loads(lines[-1])
-        keep = {k_: d.get(k_) for k_ in ("value", "ms_per_step", "verified", "headline_detail")}
+        keep = {k_: d.get(k_) for k_ in ("value", "ms_per_step", "verified", "headline_detail", "n_gpus")}
         keep["process_model"] = d["config"]["process_model"]
         keep["exchange"] = d["config"]["exchange"]
         keep["config3_batch256"] = (d.get("extra") or {}).get("config3_batch256")
@@ -597,15 +632,23 @@ def main():
         except Exception:
             host = None
     sh = build_shard(torch, args, args.rows, rank, world, device, host=host, timing=world > 1)
-    dt, prof, last, qi = run_steps(torch, dist, sh, qs, args.k, args.steps, args.warmup, world, device, ctl=ctl)
+    # >= 20 timed scan launches for `roofline`: every 4th launch by default, more often when steps x repeats is small
+    every = max(1, min(PROFILE_EVERY, (args.steps * max(1, args.repeats)) // 20))
+    dt, prof, last, qi, dts = run_steps(torch, dist, sh, qs, args.k, args.steps, args.warmup, world, device, every=every, ctl=ctl, repeats=args.repeats)
     gpu_ids, gpu_sc, same = verify_last_batch(sh, last, qs[qi].cpu().numpy(), args.k)
     if qi != 0:                 # recall is computed for batch 0 (the CPU ranking of one batch is the expensive part)
         gpu_ids = sh.search(qh, args.k)[0]
-    head = summarise(args.batch, args.steps, dt, prof, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_active")))
+    head = summarise(args.batch, args.steps, dt, prof, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_active")), dts=dts)
+    generator = _generator_note()
     out = {
         "metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (" (numpy default_rng([1234, block]) rows, SURVEY 8d)" if SURVEY_RNG else ""),
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic; corpus rows drawn by " + generator,
+        "repeats": len(dts), "value_min": head.get("value_min", head["value"]), "value_max": head.get("value_max", head["value"]),
+        "ms_per_step_min": head.get("ms_per_step_min", head["ms_per_step"]), "ms_per_step_max": head.get("ms_per_step_max", head["ms_per_step"]),
+        "ms_per_step_all": head.get("ms_per_step_all", [head["ms_per_step"]]),
+        "timing_note": f"the timed region (exactly {args.steps} steps between barrier + synchronize, max over ranks) ran {len(dts)} times back to back after one "
+                       "warm-up; value / ms_per_step are the MEDIAN region, min / max over the regions beside them",
         "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} "
                                f"(north_star target config; corpus fixed, row-sharded over {world} GPU(s))",
                    "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "query_batches_rotated": len(qs),
@@ -616,7 +659,7 @@ def main():
                      "frac_of_achievable_6290": head["hbm_GBps"] / HBM_ACHIEVABLE_GBS, "traffic": None,
                      "kernel": "scan_kernel (fused MFMA scan + top-k)", "kernel_ms": head["kernel_ms"], "two_scan_streams": head["two_scan_streams"],
                      "achieved_is": "algorithmic bytes / step time (launches overlap: no per-launch duration)" if head["two_scan_streams"] else "algorithmic bytes / HIP-event time of the scan on its stream",
-                     "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"], "timed_every": PROFILE_EVERY,
+                     "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"], "timed_every": every,
                      "rows_per_gpu": len(sh)},
         "verified": {"last_pipelined_batch_equals_synchronous_search": same},
     }
@@ -639,9 +682,9 @@ def main():
             q256 = make_queries(torch, max(1, min(args.query_batches, 3)), 256, args.dim, device, 8765)
             steps_w = max(10, args.steps // 2)
             shw = sh.view(ex256, timing=world > 1) if world > 1 else sh
-            dtw, profw, lastw, qiw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl)
+            dtw, profw, lastw, qiw, dtsw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl, repeats=min(3, max(1, args.repeats)))
             _, _, same_w = verify_last_batch(shw, lastw, q256[qiw].cpu().numpy(), args.k)
-            c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_wide_active")))
+            c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_wide_active")), dts=dtsw)
             c3["kernel"] = "scan_wide_kernel (256 queries resident in registers, LDS-DMA corpus ring)"
             c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
             c3["last_pipelined_batch_equals_synchronous_search"] = same_w
@@ -738,8 +781,8 @@ def main():
                     continue
                 qq = q if b2 == args.batch else q256
                 steps2 = max(args.steps, 100)
-                dt2, prof2, _, _ = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device)
-                extra[f"{name}_{rows2}_rows_batch{b2}"] = summarise(b2, steps2, dt2, prof2, rows2, args.dim,
+                dt2, prof2, _, _, dts2 = run_steps(torch, dist, sh2, qq, args.k, steps2, args.warmup, 1, device, repeats=min(3, max(1, args.repeats)))
+                extra[f"{name}_{rows2}_rows_batch{b2}"] = summarise(b2, steps2, dt2, prof2, rows2, args.dim, dts=dts2,
                                                                      dual=bool(sh2.local.get_option("pipe_dual_scan_active" if b2 <= 64 else "pipe_dual_scan_wide_active")))
             if name == "config2":
                 try:

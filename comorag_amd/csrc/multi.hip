@@ -169,6 +169,7 @@ struct cmr_mindex {
     int cur = -1;                               // shard of the open block
     long long room = 0;                         // rows left in it
     int parallel_min_shards = 3;                // per-shard worker threads issue the enqueues from this many active shards on
+    bool force_peer_staging = false;            // option "force_peer_staging": append_dev always stages through hipMemcpyPeer (see cmr_mindex_set_option)
     std::mutex wk_mu;
     std::vector<Worker*> workers;
     std::mutex pipe_mu;
@@ -376,6 +377,22 @@ int32_t cmr_mindex_set_option(cmr_mindex_t* m, const char* name, int64_t value) 
         m->parallel_min_shards = (int)std::max<int64_t>(1, value);
         return CMR_OK;
     }
+    if (n == "force_peer_staging") {
+        // cmr_mindex_append_dev: take the staging-buffer + hipMemcpyPeer branch even when source and shard share a device (legal: same
+        // device on both ends) — the only way a one-GPU box executes the cross-device append path (tests/test_multi_device_gpu.py)
+        std::unique_lock<std::shared_mutex> lk(m->mu);
+        m->force_peer_staging = value != 0;
+        return CMR_OK;
+    }
+    // Route selectors go to every shard.  Multi-shard searches call cmr_index_search_begin(take_lock = false) under m->mu SHARED and read
+    // the shards' option fields while they enqueue: the forwarding loop therefore holds m->mu EXCLUSIVELY (no search in flight while an
+    // option changes; a routing decision is never split inside one call).  The borrowed handles of cmr_mindex_shard are for reading
+    // (get_option, profile_collect) while searches run — set options through THIS function.
+    std::unique_lock<std::shared_mutex> lk(m->mu);
+    {   // throughput-mode batches whose enqueue jobs are still with the worker threads: let them finish issuing first
+        std::lock_guard<std::mutex> pg(m->pipe_mu);
+        for (PipeTicket& t : m->ticket) if (t.busy) t.latch.wait();
+    }
     for (cmr_index_t* i : m->shard) { const int rc = cmr_index_set_option(i, name, value); if (rc) return rc; }
     return CMR_OK;
 }
@@ -450,7 +467,7 @@ int32_t cmr_mindex_append_dev(cmr_mindex_t* m, const float* rows_dev, int64_t n,
     bool synced = false;
     return mindex_append(m, n, [&](int s, long long at, long long cnt) -> int {
         const float* src = rows_dev + (size_t)at * m->dim;
-        if (m->device[s] == src_device) return cmr_index_append_dev(m->shard[s], src, cnt, stream);
+        if (m->device[s] == src_device && !m->force_peer_staging) return cmr_index_append_dev(m->shard[s], src, cnt, stream);
         // the chunk's shard lives on another GPU: device-to-device copy into a staging buffer there (hipMemcpyPeer goes over
         // xGMI where the devices are peers and through the host where they are not), then a local append
         if (!synced) { M_HIP_TRY(hipSetDevice(src_device)); M_HIP_TRY(hipStreamSynchronize((hipStream_t)stream)); synced = true; }
@@ -669,6 +686,8 @@ int32_t cmr_mindex_search_pipelined(cmr_mindex_t* m, const float* const* q_dev, 
         M_HIP_TRY(hipHostMalloc(&t.h, need, hipHostMallocPortable | hipHostMallocMapped));
         t.cap = need;
     }
+    // everything that can fail comes BEFORE the slot is claimed: on an error the caller's *ticket stays as it was and no ring position is used up
+    if (A > 0) { const int rcw = ensure_workers(m); if (rcw) return rcw; }
     t.nq = nq; t.k = k; t.active = act;
     t.done.assign((size_t)A, nullptr);
     t.rc.assign((size_t)A, 0);
@@ -677,8 +696,6 @@ int32_t cmr_mindex_search_pipelined(cmr_mindex_t* m, const float* const* q_dev, 
     ++m->next_ticket;
     *ticket = &t;
     if (A == 0) { t.latch.arm(0); return CMR_OK; }
-    int rc = ensure_workers(m);
-    if (rc) { t.busy = false; return rc; }
     void* hbase = t.h;
     const size_t o_sc = (size_t)A * nk * 8, o_mn = (size_t)A * nk * 12, o_mx = o_mn + (size_t)A * nq * 4;
     t.latch.arm(A);

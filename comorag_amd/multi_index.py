@@ -23,15 +23,18 @@ from . import _lib as L
 from .index import DenseIndex, _f32c, _ptr
 
 
-MULTI_ONLY_OPTIONS = ("append_block_rows", "parallel_min_shards")
+MULTI_ONLY_OPTIONS = ("append_block_rows", "parallel_min_shards", "force_peer_staging")
 
 
 def resolve_devices(num_shards: Optional[int] = None, devices: Optional[Sequence[int]] = None, device: int = 0) -> List[int]:
-    """The device of every shard.  devices given: as they are (num_shards, when also given, must match or be a multiple:
-    the list is cycled).  Only num_shards: shards go round the visible devices starting at `device`."""
+    """The device of every shard.  devices given: as they are; num_shards, when also given, must equal len(devices) or be a
+    multiple of it (the list is cycled: logical shards) — anything else would silently drop or unbalance GPUs and raises.
+    Only num_shards: shards go round the visible devices starting at `device`."""
     if devices is not None and len(devices) > 0:
         devs = [int(d) for d in devices]
-        if num_shards and num_shards != len(devs):
+        if num_shards and int(num_shards) != len(devs):
+            if int(num_shards) % len(devs) != 0:
+                raise ValueError(f"num_shards = {num_shards} is not a multiple of len(devices) = {len(devs)}: shards would drop or unbalance devices")
             devs = [devs[i % len(devs)] for i in range(int(num_shards))]
         return devs
     s = int(num_shards or 1)
@@ -72,7 +75,8 @@ class MultiDeviceIndex:
         return n.value
 
     def set_option(self, name: str, value: int) -> None:
-        """"append_block_rows" / "parallel_min_shards", or any route selector of `DenseIndex.set_option` (goes to every shard)."""
+        """"append_block_rows" / "parallel_min_shards" / "force_peer_staging", or any route selector of `DenseIndex.set_option` (goes to
+        every shard, with no search in flight)."""
         L.check(L.lib().cmr_mindex_set_option(self._h, name.encode(), int(value)))
 
     def shard_rows(self) -> List[int]:
@@ -87,7 +91,8 @@ class MultiDeviceIndex:
         return b.value
 
     def shard(self, s: int) -> DenseIndex:
-        """Borrowed `DenseIndex` view of shard s (profiling, route selectors).  Never append to it."""
+        """Borrowed `DenseIndex` view of shard s (profiling, reading options).  Never append to it; while other threads search, set
+        route selectors through `MultiDeviceIndex.set_option` (exclusive over the whole handle), not on this view."""
         h = C.c_void_p()
         L.check(L.lib().cmr_mindex_shard(self._h, int(s), C.byref(h)))
         return DenseIndex._borrow(h, self.dim, self.dtype, self.devices[s], owner=self)
@@ -241,9 +246,13 @@ def _host_profile(self, reset: bool = True) -> dict:
 MultiDeviceIndex.host_profile = _host_profile
 
 
-def plan_append(shard_rows: Sequence[int], m: int, block_rows: int = 8192, cur: int = -1, room: int = 0):
+DEFAULT_APPEND_BLOCK_ROWS = 65536       # = cmr_mindex::block_rows (csrc/multi.hip), the library's "append_block_rows" default
+
+
+def plan_append(shard_rows: Sequence[int], m: int, block_rows: int = DEFAULT_APPEND_BLOCK_ROWS, cur: int = -1, room: int = 0):
     """The library's append routing on its own (cmr_mindex_plan_append; pure host arithmetic, runs without a GPU):
-    -> ([(shard, rows), ...], new_cur, new_room)."""
+    -> ([(shard, rows), ...], new_cur, new_room).  `block_rows` defaults to the library's own "append_block_rows" default, so a
+    model of the routing built with this function agrees with a real `MultiDeviceIndex` that was left at its defaults."""
     s = len(shard_rows)
     sizes = (C.c_int64 * s)(*[int(x) for x in shard_rows])
     cap = max(8, 2 * s + int(m) // max(1, int(block_rows)) + 4)

@@ -299,8 +299,11 @@ int32_t cmr_comm_allgather_merge(cmr_comm_t* comm, const int64_t* ids_dev, const
  *   search_pipelined + collect   throughput mode: q_dev[s] = the batch's queries on shard s's device (entries of empty shards are
  *               ignored); returns at once with a ticket, up to four tickets may be uncollected; collect waits for the shards,
  *               merges on the host and frees the ticket.  k <= CMR_MAX_K.
- *   set_option  "append_block_rows", "parallel_min_shards" (default 3), anything else goes to every shard (cmr_index_set_option).
- *   shard       borrow shard s (profiling, options, tests).  Do NOT append to it or re-base it directly.
+ *   set_option  "append_block_rows", "parallel_min_shards" (default 3), "force_peer_staging" (1: append_dev stages every chunk through
+ *               hipMemcpyPeer even when source and shard share a device — how a one-GPU box executes the cross-device append path);
+ *               anything else goes to every shard (cmr_index_set_option) with NO search in flight (exclusive over the handle).
+ *   shard       borrow shard s (profiling, reading options, tests).  Do NOT append to it or re-base it directly, and set route
+ *               selectors through cmr_mindex_set_option, not on the borrowed handle, while other threads search.
  * cmr_mindex_plan_append is the routing rule on its own (pure host arithmetic, no device): chunks (shard, rows) for m appended
  * rows given the shards' sizes and the open block (cur_shard, cur_room); n_chunks always returns the chunk count.            */
 typedef struct cmr_mindex cmr_mindex_t;

@@ -63,3 +63,33 @@ def test_bench_single_process_mode_four_logical_shards():
     assert out["config"]["shard_rows"] == [150000] * 4
     assert out["verified"] == {"last_pipelined_batch_equals_synchronous_search": True, "batch256_last_pipelined_batch_equals_synchronous_search": True}
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.timeout(1500)
+def test_bench_eight_ranks_sharing_one_gpu():
+    """The driver's 8-GPU command line in the only form a one-GPU box can run: `bench.py --gpus 8 --backend gloo --share-device`
+    starts EIGHT ranks (one process each, all on cuda:0, an eighth of the rows each), runs the timed regions at B = 64 and B = 256
+    with the packed candidate exchange, gathers the per-rank rows, and rank 0 then drives the same workload through ONE process with
+    eight logical shards.  Asserts the JSON line's multi-rank fields end to end: `per_rank` x 8, `exchange_bindings`,
+    `single_process`, every `verified` bit."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--share-device", "--rows", "80000",
+                        "--steps", "4", "--warmup", "1", "--repeats", "2"], capture_output=True, text=True, timeout=1400, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 4 and out["repeats"] == 2 and out["value"] > 0
+    assert out["value_min"] <= out["value"] <= out["value_max"] and len(out["ms_per_step_all"]) == 2
+    assert all(v is True for v in out["verified"].values()) and len(out["verified"]) == 2, out["verified"]
+    eb = out["exchange_bindings"]
+    assert eb["backend"] == "gloo" and eb["torch_world_size"] == 8 and eb["share_device"] is True and eb["batch64"] == "torch" and eb["batch256"] == "torch"
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and [p["rows"] for p in out["per_rank"]] == [10000] * 8
+    assert all(p["batch64"] and p["batch256"] for p in out["per_rank"])
+    assert out["roofline"]["rows_per_gpu"] == 10000 and out["config"]["sharding"] == "rows/8"
+    sp = out["single_process"]
+    assert "error" not in sp, sp
+    assert sp["n_gpus"] == 8 and sp["value"] > 0 and "one process, 8 shard(s)" in sp["process_model"]
+    assert all(v is True for v in sp["verified"].values()) and len(sp["verified"]) == 2

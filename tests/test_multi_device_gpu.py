@@ -313,3 +313,34 @@ def test_device_rows_append_equals_host_rows_append():
         assert np.array_equal(x, y)
     assert np.array_equal(a.get_rows(np.arange(0, 6_000, 97)), b.get_rows(np.arange(0, 6_000, 97)))
     a.close(); b.close()
+
+
+def test_device_rows_append_through_the_peer_staging_branch():
+    """The cross-device branch of cmr_mindex_append_dev (wait for the source stream, hipMalloc of a staging buffer on the shard's
+    device, hipMemcpyPeer, local append, hipFree) has no second GPU to run on here; option "force_peer_staging" sends EVERY chunk
+    through it with the same device on both ends (legal for hipMemcpyPeer).  Same rows, same global ids, same results as the
+    in-place route — incl. rows produced on a side stream that the branch must wait for."""
+    import torch
+    from comorag_amd.multi_index import MultiDeviceIndex
+    d = 256
+    X = orc.synthetic_corpus(6_000, d, seed=197)
+    Q = orc.synthetic_queries(8, d, seed=198, planted=X)
+    a = MultiDeviceIndex(d, "bf16", devices=[0] * 4, options={"append_block_rows": 128})
+    b = MultiDeviceIndex(d, "bf16", devices=[0] * 4, options={"append_block_rows": 128, "force_peer_staging": 1})
+    side = torch.cuda.Stream()
+    at = 0
+    for n in (3_000, 25, 25, 1_000, 1, 1_949):
+        a.append(X[at:at + n])
+        with torch.cuda.stream(side):                 # the rows are still being written on `side` when append_dev is called
+            t = torch.from_numpy(X[at:at + n]).cuda(non_blocking=True) * 1.0
+        b.append_dev(t, stream=side.cuda_stream)
+        at += n
+    assert a.shard_rows() == b.shard_rows() and len(b) == len(X)
+    for x, y in zip(a.search(Q, 20), b.search(Q, 20)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.get_rows(np.arange(0, 6_000, 97)), b.get_rows(np.arange(0, 6_000, 97)))
+    b.set_option("force_peer_staging", 0)              # and back: the in-place route on the same handle
+    b.append_dev(torch.from_numpy(X[:300]).cuda()); a.append(X[:300])
+    for x, y in zip(a.search(Q, 20), b.search(Q, 20)):
+        assert np.array_equal(x, y)
+    a.close(); b.close()

@@ -76,6 +76,10 @@ def test_resolve_devices_and_config_fields():
     assert resolve_devices(devices=[0, 0, 1]) == [0, 0, 1]
     assert resolve_devices(num_shards=4, devices=[2, 3]) == [2, 3, 2, 3]
     assert len(resolve_devices(num_shards=8)) == 8 and len(resolve_devices()) == 1
+    import pytest
+    for bad in (2, 3, 6):                       # would drop or unbalance GPUs of a four-device list: refused, not truncated
+        with pytest.raises(ValueError):
+            resolve_devices(num_shards=bad, devices=[0, 1, 2, 3])
     cfg = BaseConfig()
     assert cfg.num_shards == 1 and cfg.devices is None and cfg.index_options is None          # reference behaviour by default
     assert cfg.embedding_model_name == "nvidia/NV-Embed-v2"                                  # utils/config_utils.py:128-129 of the reference
