@@ -840,7 +840,7 @@ def main():
         rows = (("config4_probe_loop", lambda: bx.config4_probe_loop(torch, device, dim=args.dim, dtype=args.dtype, rows0=min(2_000_000, max(args.rows, 200_000)), k=args.k)),
                 ("corpus_embed", lambda: bx.encode_breakdown(torch, device, "base", "auto", 128)[0]),
                 ("corpus_embed_bf16", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 1024)[0]),
-                ("corpus_embed_bf16_tokenizer_processes", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 1024, tok_processes=4)[0]),
+                ("corpus_embed_bf16_tokenizer_threads_only", lambda: bx.encode_breakdown(torch, device, "base", "bf16", 1024, tok_processes=0)[0]),
                 ("config5_bge_large_fp16_encode_search_rescore", lambda: bx.config5_encode_search_rescore(torch, device)),
                 ("f1_synonymy_selfjoin", lambda: bx.f1_selfjoin(torch, device, dim=args.dim)),
                 ("f4_dpr_seeded_ppr", lambda: bx.f4_ppr(torch, device)))
@@ -864,6 +864,10 @@ def main():
                 "config2_1M_rows_qps": _get(extra, f"config2_{min(args.rows, 1_000_000)}_rows_batch{args.batch}", "value"),
                 "shard_1p25M_rows_batch256_ms_per_step": _get(extra, f"config3_one_of_8_shards_{min(args.rows, 1_250_000)}_rows_batch256", "ms_per_step"),
                 "corpus_embed_bf16_chunks_per_s": _get(extra, "corpus_embed_bf16", "value"),
+                "corpus_embed_bf16_forward_only_chunks_per_s": _get(extra, "corpus_embed_bf16", "forward_only_chunks_per_s"),
+                "corpus_embed_bf16_end_to_end_over_forward_only": _get(extra, "corpus_embed_bf16", "end_to_end_over_forward_only"),
+                "config5_bge_large_fp16_chunks_per_s": _get(extra, "config5_bge_large_fp16_encode_search_rescore", "encode", "value"),
+                "config5_end_to_end_over_forward_only": _get(extra, "config5_bge_large_fp16_encode_search_rescore", "encode", "end_to_end_over_forward_only"),
                 "single_query_latency_1M_rows_us": _get(extra, "single_query_latency", "rows", str(min(args.rows, 1_000_000))),
                 "config4_search_us_per_call": _get(extra, "config4_probe_loop", "search_us_per_call"),
                 "config4_call_frac_of_hbm": _get(extra, "config4_probe_loop", "frac")}

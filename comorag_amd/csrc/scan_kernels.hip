@@ -56,6 +56,30 @@
 #ifndef CMR_WIDE_DMA_BURST
 #define CMR_WIDE_DMA_BURST 0
 #endif
+// Placement of a quad's LDS-DMA piece in the two-tile wide kernel.  0: in front of the quad's eight MFMAs, i.e. directly behind
+// the four ds_read_b128 that refill the read-ahead ring (one boundary of the MFMA stream carries 4 LDS reads + the piece + its
+// SALU: a dozen issue slots in ONE gap).  1: between tile 0's four MFMAs and tile 1's four — the other boundary between chains
+// on DIFFERENT accumulators, 128 cycles behind the ring's reads (MI355X_MICROARCH.md: a gap between MFMAs hides <= 5 single-issue
+// instructions, fillers between MFMAs on the SAME accumulator are never free, and a piece issued beside pending LDS reads
+// costs its wave 100-185 cycles against 25-60 in a quiet gap).
+#ifndef CMR_WIDE_DMA_MID
+#define CMR_WIDE_DMA_MID 1
+#endif
+// M0 around a piece: 0 = saved and restored inside the statement (5 instructions), 1 = written and left (3; hipcc sets M0 itself
+// in front of each of its own uses — v_writelane lane selects in the compaction — and expects nothing of it across an asm)
+#ifndef CMR_WIDE_M0_CLOBBER
+#define CMR_WIDE_M0_CLOBBER 1
+#endif
+// 1: a piece's displacement inside its group comes from the instruction's immediate + a loop-invariant lane offset, M0 is set inside
+// the statement: no compiler-generated SALU per piece (see dma_piece_j)
+#ifndef CMR_WIDE_DMA_IMM
+#define CMR_WIDE_DMA_IMM 1
+#endif
+// 1: the read-ahead ring's slot j is refilled directly behind the LAST tile's MFMA j of a quad (the slot's final reader), where the
+// wait state between two MFMAs of one chain is due anyway, instead of four ds_read_b128 in a row behind the quad
+#ifndef CMR_WIDE_READ_INTERLEAVE
+#define CMR_WIDE_READ_INTERLEAVE 1
+#endif
 
 struct ScanP {
     const v4u* corpus;
@@ -1222,10 +1246,42 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
         const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u;
         // one DMA piece: 1 KiB from (wave-uniform base + voff) to LDS byte address dst
         auto dma_piece = [&](const char* base, unsigned dst) {
+#if CMR_WIDE_M0_CLOBBER
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" CMR_STREAM_POLICY
+                         :: "v"(voff), "s"(base), "s"(dst) : "memory", "m0");
+#else
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" CMR_STREAM_POLICY "\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
+#endif
         };
+#if CMR_WIDE_DMA_IMM
+        // Piece j of a group WITHOUT compiler arithmetic around it (4-wave kernel: pieces are 4 KiB apart): the group's source base and
+        // LDS destination are two SGPR operands shared by all its pieces; the piece's own displacement is split between three
+        // loop-invariant lane offsets (voff + 4 KiB, + 12 KiB, + 20 KiB) and the instruction's signed 13-bit immediate (-4096 / 0), M0
+        // takes destination + j * 4 KiB inside the statement.  Three issue slots per piece, none of them hipcc's to place: left to the
+        // compiler, the 64-bit source add and the destination add of every piece land in the gaps of the neighbouring MFMA chain.
+        // The instruction's immediate displaces BOTH addresses of an LDS-DMA — the global source and the LDS destination (M0 + offset
+        // + lane * 16; measured: without the correction every second piece lands 4 KiB low and the results differ) — so M0 is set to
+        // destination + j * 4 KiB MINUS the immediate.
+        unsigned voj0 = voff + 4096u, voj1 = voff + 3u * 4096u, voj2 = voff + 5u * 4096u;
+        asm volatile("" : "+v"(voj0), "+v"(voj1), "+v"(voj2));      // three registers, not three adds per use
+#define CMR_WIDE_PIECE(J, VO)                                                                                                          \
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%4" CMR_STREAM_POLICY                      \
+                 :: "v"(VO), "s"(gb), "s"(gd), "n"((J) * 4096 - (((J) & 1) ? 0 : -4096)), "n"(((J) & 1) ? 0 : -4096) : "memory", "m0", "scc")
+        auto dma_piece_j = [&](int j, const char* gb, unsigned gd) __attribute__((always_inline)) {
+            static_assert(NW != 4 || PPG <= 6, "six pieces per group at most");
+            switch (j) {            // j is a constant after unrolling: one statement survives
+                case 0: CMR_WIDE_PIECE(0, voj0); break;
+                case 1: CMR_WIDE_PIECE(1, voj0); break;
+                case 2: CMR_WIDE_PIECE(2, voj1); break;
+                case 3: CMR_WIDE_PIECE(3, voj1); break;
+                case 4: CMR_WIDE_PIECE(4, voj2); break;
+                default: CMR_WIDE_PIECE(5, voj2); break;
+            }
+        };
+#undef CMR_WIDE_PIECE
+#endif
         // prologue: groups 0 .. NST-2 of this workgroup's stream (clamped to its last group)
 #pragma unroll
         for (int d = 0; d < NST - 1; ++d) {
@@ -1309,17 +1365,32 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
                 // matrix pipe has (tools/probe/mfma_probe.hip: 1.45 PFLOP/s chip-wide against 1.83 for runs of four).
 #pragma unroll
                 for (int qd = 0; qd < GRP / 4; ++qd) {
-                    if (ABL != 2 && ABL != 6 && ABL != 7) {
-                        if (CMR_WIDE_DMA_BURST) {
-                            if (qd == 0)
-                                for (int j = 0; j < PPG; ++j) dma_piece(dsrc + j * NW * 1024, ddst + (unsigned)j * NW * 1024u);
-                        } else if (qd % QPP == 0) {
-                            dma_piece(dsrc + (qd / QPP) * NW * 1024, ddst + (unsigned)(qd / QPP) * NW * 1024u);
+                    constexpr bool DMA_MID = NT == 2 && CMR_WIDE_DMA_MID && !CMR_WIDE_DMA_BURST;
+                    auto quad_dma = [&]() __attribute__((always_inline)) {
+                        if (ABL != 2 && ABL != 6 && ABL != 7) {
+                            if (CMR_WIDE_DMA_BURST) {
+                                if (qd == 0)
+                                    for (int j = 0; j < PPG; ++j) dma_piece(dsrc + j * NW * 1024, ddst + (unsigned)j * NW * 1024u);
+                            } else if (qd % QPP == 0) {
+#if CMR_WIDE_DMA_IMM
+                                if constexpr (NW == 4) dma_piece_j(qd / QPP, dsrc, ddst);
+                                else
+#endif
+                                dma_piece(dsrc + (qd / QPP) * NW * 1024, ddst + (unsigned)(qd / QPP) * NW * 1024u);
+                            }
                         }
-                    }
+                    };
+                    if constexpr (!DMA_MID) quad_dma();
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (DMA_MID) {
+                            if (t == 1) {           // the boundary between the two tiles' chains of this quad
+                                __builtin_amdgcn_sched_barrier(0);
+                                quad_dma();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int u = qd * 4 + j;
@@ -1338,6 +1409,12 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
                             } else {
                                 const v4u b = qlds[(t * KLDS + (ks < KREG ? 0 : ks - KREG)) * 64];
                                 CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
+                            }
+                            if constexpr (CMR_WIDE_READ_INTERLEAVE && ABL != 6) {
+                                if (t == NT - 1) {
+                                    const int blk = u + ADEPTH;
+                                    a[u % ADEPTH] = blk < GRP ? buf[blk * 64] : bufn[(blk - GRP) * 64];
+                                }
                             }
                             if constexpr (NT == 2 && ABL != 3) {
                                 // (g, qd, t, j are constants after unrolling: at most one of these survives per MFMA)
@@ -1377,8 +1454,9 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
                                 }
                             }
                         }
+                    }
                     // the quad's four ring slots take the blocks ADEPTH ahead (they land under the next quad's MFMAs)
-                    if constexpr (ABL != 6) {
+                    if constexpr (ABL != 6 && !CMR_WIDE_READ_INTERLEAVE) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int blk = qd * 4 + j + ADEPTH;

@@ -118,7 +118,8 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             if reason is None and getattr(tokenizer, "padding_side", "right") != "right":
                 reason = "left-padding tokenizer"
             if reason is None:
-                self._fused = fused_bert.FusedBertLayers(self.embedding_model, graphs=int(cfg_get(self.global_config, "embedding_hip_graphs", 24)))
+                self._fused = fused_bert.FusedBertLayers(self.embedding_model, graphs=int(cfg_get(self.global_config, "embedding_hip_graphs", 24)),
+                                                         gelu=str(cfg_get(self.global_config, "embedding_gelu", "epilogue")))
                 self.encoder_path = "hip-fused-layers"
             else:
                 self.encoder_path = f"transformers ({reason})"
@@ -139,20 +140,45 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         import threading
         self._fast_tok = hasattr(tokenizer, "backend_tokenizer") and hasattr(tokenizer.backend_tokenizer, "to_str")
         self._bt_copies, self._bt_lock = {}, threading.Lock()
-        self._tok_procs = None
-        n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", 0) or 0)
+        # -1 (default): processes are started by the first corpus-sized batch_encode call (>= two bucketing windows of texts), in the
+        # background — that call goes on with threads until the workers answer; 0: threads only; N > 0: N processes from the start.
+        self._tok_procs, self._tok_procs_starting = None, None
+        n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", -1))
+        self._tok_procs_auto = (min(4, max(1, (os.cpu_count() or 2) // 4)) if n_procs < 0 else 0) if self._fast_tok else 0
         if n_procs > 0 and self._fast_tok:
-            import multiprocessing as mp
-            from . import _tokworker
-            self._tok_procs = mp.get_context("spawn").Pool(min(n_procs, os.cpu_count() or 1), initializer=_tokworker.init,
-                                                           initargs=(tokenizer.backend_tokenizer.to_str(), getattr(tokenizer, "truncation_side", "right"),
-                                                                     "longest_first"))
+            self._tok_procs = self._start_tok_procs(n_procs)
         self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
         if self._cached:
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
             self.encode = make_cache_embed(self._encode, path, self.device)
         else:
             self.encode = self._encode
+
+    def _start_tok_procs(self, n: int):
+        """A pool of spawned, tokenizers-only worker processes (_tokworker.py), answering before it is handed out."""
+        import multiprocessing as mp
+        import os
+        from . import _tokworker
+        tok = self.tokenizer
+        pool = mp.get_context("spawn").Pool(min(int(n), os.cpu_count() or 1), initializer=_tokworker.init,
+                                            initargs=(tok.backend_tokenizer.to_str(), getattr(tok, "truncation_side", "right"), "longest_first"))
+        pool.apply(_tokworker.ragged, (["warm up"], 16))        # the workers have imported `tokenizers` and rebuilt the tokenizer
+        return pool
+
+    def _maybe_start_tok_procs(self, n_texts: int, window_texts: int) -> None:
+        """embedding_tokenizer_processes = -1: a corpus-sized call (>= two windows) starts the worker processes on a background
+        thread; whichever call finds them answering uses them from its next window on."""
+        if self._tok_procs is not None or not self._tok_procs_auto or self._tok_procs_starting is not None or n_texts < 2 * window_texts:
+            return
+        import threading
+
+        def _go():
+            try:
+                self._tok_procs = self._start_tok_procs(self._tok_procs_auto)
+            except Exception:                     # no worker processes on this host: the threads stay
+                self._tok_procs_auto = 0
+        self._tok_procs_starting = threading.Thread(target=_go, name="cmr-tok-procs", daemon=True)
+        self._tok_procs_starting.start()
 
     def _init_embedding_config(self) -> None:
         self.embedding_config = EmbeddingConfig.from_dict({
@@ -304,14 +330,16 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     left -= sizes[-1]
                 starts = np.cumsum([0] + sizes[:-1])
                 windows = [chunks[a:a + n] for a, n in zip(starts, sizes)]
-                if self._tok_procs is not None:
-                    from . import _tokworker
-                    submit = lambda w: [self._tok_procs.apply_async(_tokworker.ragged, ([instr + t for t in c] if instr else list(c), ml)) for c in w]
-                    collect = lambda jobs: [x for j in jobs for x in j.get()]
-                else:
-                    rag = lambda c: self._ragged([instr + t for t in c] if instr else list(c), ml)
-                    submit = lambda w: [self._tok_pool.submit(rag, c) for c in w]
-                    collect = lambda jobs: [x for j in jobs for x in j.result()]
+                from . import _tokworker
+                self._maybe_start_tok_procs(len(texts), win * batch_size)
+                rag = lambda c: self._ragged([instr + t for t in c] if instr else list(c), ml)
+
+                def submit(w):      # worker processes as soon as they answer (the Rust tokenizer holds the GIL: threads share the launching core)
+                    procs = self._tok_procs
+                    if procs is not None:
+                        return [procs.apply_async(_tokworker.ragged, ([instr + t for t in c] if instr else list(c), ml)) for c in w]
+                    return [self._tok_pool.submit(rag, c) for c in w]
+                collect = lambda jobs: [x for j in jobs for x in (j.get() if hasattr(j, "get") else j.result())]
                 look = 3                                   # windows being tokenised ahead of the one on the GPU
                 pending = [submit(w) for w in windows[:look]]
                 # token budget of a mini-batch: `embedding_forward_batches` reference batches' worth.  The GEMMs of a 128 x 512-token
@@ -379,6 +407,10 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
     def close(self) -> None:
         if getattr(self, "_fused", None) is not None:
             self._fused.release()
+        starting = getattr(self, "_tok_procs_starting", None)
+        if starting is not None and starting.is_alive():
+            starting.join(30.0)                   # a pool still being spawned: let it finish, then take it down with the rest
+        self._tok_procs_auto = 0
         if getattr(self, "_tok_procs", None) is not None:
             self._tok_procs.terminate()
             self._tok_procs = None

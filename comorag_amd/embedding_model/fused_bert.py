@@ -6,7 +6,7 @@ mask, the output GEMM, bias / residual adds, LayerNorm, the FFN GEMMs and GELU. 
     qkv  = x @ [Wq | Wk | Wv]^T + b          one hipBLASLt GEMM instead of three (PyTorch-ROCm, as north_star prescribes)
     ctx  = cmr_encoder_attention(qkv, lens)   HIP: masked softmax(QK^T/8)V straight off the packed projection, no head transposes
     x    = cmr_encoder_add_layernorm(ctx @ Wo^T, bo, x)       HIP: dense bias + residual + LayerNorm in one pass
-    x    = cmr_encoder_add_layernorm(gelu(x @ W1^T + b1) @ W2^T, b2, x)
+    x    = cmr_encoder_add_layernorm(gelu(x @ W1^T + b1) @ W2^T, b2, x)      (bias + GELU in the up-projection GEMM's epilogue)
 
 seven host calls per layer — and ONE per forward once a mini-batch shape has been captured as a hipGraph (`graphs`) — so the
 thread that launches the forward leaves the interpreter lock to the tokenizer threads.
@@ -79,12 +79,43 @@ def lens_of_mask(mask: np.ndarray) -> Optional[np.ndarray]:
     return lens if np.all(lens > 0) else None
 
 
+def gelu_epilogue_available(device, dtype) -> bool:
+    """Does this PyTorch-ROCm build run `torch._addmm_activation(bias, x, w.T, use_gelu=True)` as ONE hipBLASLt GEMM whose epilogue
+    adds the bias and applies GELU in its tanh form?  Checked on the device: the call must agree with tanh-GELU of the same
+    linear map to within a 16-bit rounding step and must NOT agree better with the erf form (a build that falls back to a
+    separate exact-GELU kernel gains nothing and is left on the exact path)."""
+    import torch
+    import torch.nn.functional as F
+    if not hasattr(torch, "_addmm_activation"):
+        return False
+    try:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        x = (torch.randn((256, 256), generator=g) * 1.5).to(device=device, dtype=dtype)
+        w = (torch.randn((512, 256), generator=g) / 16.0).to(device=device, dtype=dtype)
+        b = torch.randn((512,), generator=g).to(device=device, dtype=dtype)
+        got = torch._addmm_activation(b, x, w.t(), use_gelu=True).float()
+        lin = F.linear(x.float(), w.float(), b.float())
+        want_tanh, want_erf = F.gelu(lin, approximate="tanh"), F.gelu(lin)
+        step = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+        tol = step * (1.0 + want_tanh.abs())
+        ok = bool(((got - want_tanh).abs() <= tol).all())
+        return ok and float((got - want_tanh).abs().mean()) <= float((got - want_erf).abs().mean())
+    except Exception:
+        return False
+
+
 class FusedBertLayers:
-    def __init__(self, model, graphs: int = 0):
+    def __init__(self, model, graphs: int = 0, gelu: str = "epilogue"):
+        """gelu = "epilogue": the FFN-up projection, its bias and GELU are ONE hipBLASLt GEMM (`torch._addmm_activation`, GELU
+        in hipBLASLt's tanh form: |tanh-form - erf-form| <= 4.8e-4, below the 16-bit rounding of the activation it feeds —
+        tests/test_encoder_fused_gpu.py holds the stack to the same 1e-3 bars either way); falls back to "exact" when the build
+        does not fuse it (`gelu_path` says which one runs).  gelu = "exact": GEMM + bias, then PyTorch's erf-form GELU kernel."""
         import torch
         reason = why_not(model)
         if reason is not None:
             raise ValueError("FusedBertLayers: " + reason)
+        if gelu not in ("epilogue", "exact"):
+            raise ValueError("FusedBertLayers: gelu must be 'epilogue' or 'exact'")
         self.model = model
         cfg = model.config
         self.hidden, self.n_heads, self.eps = int(cfg.hidden_size), int(cfg.num_attention_heads), float(cfg.layer_norm_eps)
@@ -95,6 +126,7 @@ class FusedBertLayers:
         self.emb = tuple(t.detach().contiguous() for t in (emb.word_embeddings.weight, emb.position_embeddings.weight,
                                                            emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias))
         self.pos_offset = position_offset(model)
+        self.gelu_path = "hipblaslt-epilogue-tanh" if (gelu == "epilogue" and gelu_epilogue_available(self.device, self.dtype)) else "exact-erf-kernel"
         import threading
         self.fold_pool = True                        # the encoder tail (mean-pool + L2-norm) rides the last layer's LayerNorm kernel
         self.graphs = int(graphs)                    # mini-batch shapes kept as captured hipGraphs (0: every forward is launched eagerly)
@@ -207,7 +239,10 @@ class FusedBertLayers:
             qkv = F.linear(x, wqkv, bqkv)
             ctx = self.attention(qkv, lens_dev, b, l, stream)
             x = self.add_layernorm(F.linear(ctx, wo), bo, x, g1, be1, stream)
-            h = F.gelu(F.linear(x, w1, b1))
+            if self.gelu_path == "hipblaslt-epilogue-tanh":
+                h = torch._addmm_activation(b1, x, w1.t(), use_gelu=True)       # one GEMM: + bias, GELU in the epilogue
+            else:
+                h = F.gelu(F.linear(x, w1, b1))
             if n == last and pool is not None:
                 return self.add_layernorm_pool(F.linear(h, w2), b2, x, g2, be2, lens_dev, b, l, bool(pool), stream)
             x = self.add_layernorm(F.linear(h, w2), b2, x, g2, be2, stream)
