@@ -71,6 +71,16 @@ __device__ __forceinline__ float cmr_h2f(unsigned short h) { return (float)__bui
             if (ab) asm volatile(MNEMONIC " %0, %1, %2, %0" : "+a"(c) : "v"(a), "a"(b));                              \
             else asm volatile(MNEMONIC " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));                                 \
         }                                                                                                            \
+    }                                                                                                                \
+    /* the same with the accumulator in the VGPR half (its readers then need no v_accvgpr_read) */                    \
+    static __device__ __forceinline__ void mma_asm_cv(int ab, bool first, f32x16& c, const v4u& a, const v4u& b) {   \
+        if (first) {                                                                                                 \
+            if (ab) asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));                              \
+            else asm volatile(MNEMONIC " %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));                                 \
+        } else {                                                                                                     \
+            if (ab) asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));                              \
+            else asm volatile(MNEMONIC " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));                                 \
+        }                                                                                                            \
     }
 // 8-pass XDL result -> any non-MFMA reader: 12 wait states (guide §5.7 item 2); s_nop 15 = 16
 template <int NT> __device__ __forceinline__ void cmr_mfma_drain(f32x16 (&acc)[NT]) {

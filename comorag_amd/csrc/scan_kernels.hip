@@ -75,6 +75,12 @@
 #ifndef CMR_WIDE_DMA_IMM
 #define CMR_WIDE_DMA_IMM 1
 #endif
+// 1 (two-tile kernel): both tiles' accumulators live in the VGPR half — their readers (the min / max fold, the slow path) take them as
+// they are, no v_accvgpr_read: 32 fewer instructions per panel — and WIDE_AMOVE_V k-steps of tile 0's B-operands move to the AGPR half in
+// exchange (which then holds 192 + 64 registers of fragments and nothing else)
+#ifndef CMR_WIDE_ACC_VGPR
+#define CMR_WIDE_ACC_VGPR 1
+#endif
 // 1: the read-ahead ring's slot j is refilled directly behind the LAST tile's MFMA j of a quad (the slot's final reader), where the
 // wait state between two MFMAs of one chain is due anyway, instead of four ds_read_b128 in a row behind the quad
 #ifndef CMR_WIDE_READ_INTERLEAVE
@@ -936,6 +942,13 @@ __device__ __forceinline__ void wide_epi_piece(const f32x16& acc, int i, float& 
                  : "a"(acc[4 * i]), "a"(acc[4 * i + 1]), "a"(acc[4 * i + 2]), "a"(acc[4 * i + 3]));
     __builtin_amdgcn_sched_barrier(0);
 }
+// accumulators in VGPRs: the same four-value fold without the reads
+__device__ __forceinline__ void wide_epi_piece_v(const f32x16& acc, int i, float& gmax, float& mn) {
+    asm volatile("v_max3_f32 %0, %2, %3, %4\n\tv_min3_f32 %1, %1, %2, %3\n\tv_max_f32 %0, %0, %5\n\tv_min3_f32 %1, %1, %4, %5"
+                 : "=&v"(gmax), "+v"(mn)
+                 : "v"(acc[4 * i]), "v"(acc[4 * i + 1]), "v"(acc[4 * i + 2]), "v"(acc[4 * i + 3]));
+    __builtin_amdgcn_sched_barrier(0);
+}
 // the same for the corpus' last, partial panel: rows >= nvalid are padding
 __device__ __forceinline__ float wide_minmax_partial(const f32x16& acc, int nvalid, int lane, float& rmin, float& rmax) {
     float mx = -__builtin_inff(), mn = rmin;
@@ -1158,6 +1171,10 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
     constexpr int QPP = (GRP / 4) / PPG;          // quads of blocks per DMA piece of a wave (1 at 4 waves, 2 at 8)
     static_assert(PPG * QPP == GRP / 4, "DMA pieces spread evenly over the quads of a group");
     constexpr int KREG = KS - KLDS;               // k-steps of a tile resident in registers; the last KLDS sit in LDS
+    constexpr bool ACCV = NT == 2 && NW == 4 && CMR_WIDE_ACC_VGPR;     // accumulators in the VGPR half (see CMR_WIDE_ACC_VGPR)
+    constexpr int AMOVE = ACCV ? 16 : WIDE_AMOVE;                       // NT = 2: k-steps of tile 0 whose B-operand lives in the AGPR half
+// an empty / nop statement that makes an accumulator opaque at this point, whichever register file holds it
+#define CMR_ACC_ASM(TEXT, C) do { if constexpr (ACCV) asm volatile(TEXT : "+v"(C)); else asm volatile(TEXT : "+a"(C)); } while (0)
     constexpr int VK = NW == 8 ? (KS - KLDS) - 28 : KS / 2;     // NT = 1: k-steps whose B-operand lives in the VGPR half (the rest: AGPRs; hipcc splits a 256-register budget 128 / 128: 16 accumulators + 28 k-steps fill the AGPR half exactly)
 
     v4u* stage_lds = reinterpret_cast<v4u*>(smem);                                    // [NST][GRP][64]
@@ -1307,7 +1324,8 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
         // panel's after the loop.  No accumulator is duplicated; the threshold test and the (rare) slow path follow the
         // fold at once, so a tile's pushes still precede the next panel's compare for that tile.
         f32x16 acc[NT];
-        if constexpr (NT == 2) asm volatile("" : "=a"(acc[1]));   // the very first quad folds (and discards) whatever is there
+        if constexpr (ACCV) asm volatile("" : "=v"(acc[1]));
+        else if constexpr (NT == 2) asm volatile("" : "=a"(acc[1]));   // the very first quad folds (and discards) whatever is there
         float eg[4] = {0.0f, 0.0f, 0.0f, 0.0f}, emn = 0.0f;   // quarter maxima / panel min under construction by the interleaved pieces
         unsigned prow0 = 0;                           // the previous panel: tile 1's epilogue is still pending
         int pnvalid = CMR_PANEL_ROWS;
@@ -1317,7 +1335,8 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
             constexpr int t = decltype(tc)::value;
             float mx;
             if (__builtin_expect(nvalid < CMR_PANEL_ROWS, 0)) {        // only the corpus' last panel: masked re-computation
-                asm volatile("" : "+s"(nvalid), "+a"(acc[t]));         // keeps the masked variant's arithmetic and accumulator reads inside this branch
+                asm volatile("" : "+s"(nvalid));
+                CMR_ACC_ASM("", acc[t]);                               // keeps the masked variant's arithmetic and accumulator reads inside this branch
                 mx = wide_minmax_partial(acc[t], nvalid, lane, rmin[t], rmax[t]);
                 eg[0] = eg[1] = eg[2] = eg[3] = mx;                    // the slow path looks everywhere
             } else if (decltype(folded)::value) {
@@ -1329,11 +1348,11 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
             }
             if (ABL != 4 && __any(mx >= tau_f[t])) {
                 // (opaque: hipcc must not hoist the slow path's sixteen accumulator reads in front of the test)
-                if constexpr (decltype(folded)::value) asm volatile("" : "+a"(acc[t]));
+                if constexpr (decltype(folded)::value) CMR_ACC_ASM("", acc[t]);
                 // sampling pass: dense hits (threshold from a small sample) -> staged push; main pass: sparse hits
                 const u64 need = P.sample_waves > 0
                     ? wide_push<CAP, STG>(acc[t], row0, nvalid, tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, stg, stg_tail, lane, n_stores)
-                    : wide_push_sparse<CAP, decltype(folded)::value>(acc[t], eg, row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane, n_stores);
+                    : wide_push_sparse<CAP, decltype(folded)::value && !ACCV>(acc[t], eg, row0, nvalid, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, lane, n_stores);
                 if (need) {
                     wide_compact<CAP>(need, P.k, tau_key[t], tau_f[t], cnt_w + t * 32, list_w + (size_t)t * 32 * CAP, cstage, lane);
                     compacted = true;
@@ -1399,13 +1418,14 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
                             // register file of the resident B-operand: tile 0 in VGPRs, tile 1 in AGPRs (NT = 2); first /
                             // second half of the k-steps (NT = 1).  The accumulators are AGPRs.
                             // (WIDE_AMOVE of tile 0's operands also sit in AGPRs: the AGPR half has registers to spare)
-                            const int ab = NT == 2 ? (t == 1 || ks >= KS - WIDE_AMOVE ? 1 : 0) : (ks >= VK ? 1 : 0);
+                            const int ab = NT == 2 ? (t == 1 || ks >= KS - AMOVE ? 1 : 0) : (ks >= VK ? 1 : 0);
                             if constexpr (ABL == 1) {
                                 if (ab) asm volatile("" ::"v"(a_use), "a"(qreg[t][ks < KREG ? ks : 0]));
                                 else asm volatile("" ::"v"(a_use), "v"(qreg[t][ks < KREG ? ks : 0]));
-                                if (ks == 0) asm volatile("" : "=a"(acc[t]));
+                                if (ks == 0) { if constexpr (ACCV) asm volatile("" : "=v"(acc[t])); else asm volatile("" : "=a"(acc[t])); }
                             } else if (ks < KREG) {
-                                CmrBlk<DT>::mma_asm(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
+                                if constexpr (ACCV) CmrBlk<DT>::mma_asm_cv(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
+                                else CmrBlk<DT>::mma_asm(ab, ks == 0, acc[t], a_use, qreg[t][ks < KREG ? ks : 0]);
                             } else {
                                 const v4u b = qlds[(t * KLDS + (ks < KREG ? 0 : ks - KREG)) * 64];
                                 CmrBlk<DT>::mma_asm(0, ks == 0, acc[t], a_use, b);
@@ -1424,10 +1444,11 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
                                         // MFMA result -> VALU reader needs 12 wait states after the producer's issue, which hipcc does
                                         // not pad for asm: the producer (tile 1's last MFMA of the previous panel) is tile 0's tail
                                         // pieces, four LDS reads, a counted wait, a barrier, a DMA statement and an MFMA back
-                                        asm volatile("" : "+a"(acc[NT - 1]));
+                                        CMR_ACC_ASM("", acc[NT - 1]);
                                         emn = __builtin_inff();
                                     }
-                                    wide_epi_piece(acc[NT - 1], j, eg[j], emn);
+                                    if constexpr (ACCV) wide_epi_piece_v(acc[NT - 1], j, eg[j], emn);
+                                    else wide_epi_piece(acc[NT - 1], j, eg[j], emn);
                                     if (j == 3) {
                                         int n1 = 0;
                                         bool comp = false;
@@ -1446,11 +1467,16 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
                                     // depends on its first, so it issues >= 8 states after it whatever the pipe does with independent
                                     // MFMAs: the first piece goes behind the SECOND MFMA, two more states make 12 by construction.
                                     if (j == 1) {
-                                        asm volatile("s_nop 1" : "+a"(acc[0]));
+                                        CMR_ACC_ASM("s_nop 1", acc[0]);
                                         emn = __builtin_inff();
                                     }
-                                    if (j >= 1) wide_epi_piece(acc[0], j - 1, eg[j - 1 < 0 ? 0 : j - 1], emn);
-                                    if (j == 3) wide_epi_piece(acc[0], 3, eg[3], emn);
+                                    if constexpr (ACCV) {
+                                        if (j >= 1) wide_epi_piece_v(acc[0], j - 1, eg[j - 1 < 0 ? 0 : j - 1], emn);
+                                        if (j == 3) wide_epi_piece_v(acc[0], 3, eg[3], emn);
+                                    } else {
+                                        if (j >= 1) wide_epi_piece(acc[0], j - 1, eg[j - 1 < 0 ? 0 : j - 1], emn);
+                                        if (j == 3) wide_epi_piece(acc[0], 3, eg[3], emn);
+                                    }
                                 }
                             }
                         }
@@ -1505,10 +1531,10 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
             }
         }
         if constexpr (NT == 2 && ABL != 3) {      // tile 1 of the last panel
-            asm volatile("s_nop 15" : "+a"(acc[NT - 1]));
+            CMR_ACC_ASM("s_nop 15", acc[NT - 1]);
             emn = __builtin_inff();
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wide_epi_piece(acc[NT - 1], j, eg[j], emn);
+            for (int j = 0; j < 4; ++j) { if constexpr (ACCV) wide_epi_piece_v(acc[NT - 1], j, eg[j], emn); else wide_epi_piece(acc[NT - 1], j, eg[j], emn); }
             int n1 = 0;
             bool comp = false;
             epi_finish(T1{}, std::true_type{}, prow0, pnvalid, n1, comp);
@@ -1527,6 +1553,8 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
         }
     }
 }
+
+#undef CMR_ACC_ASM
 
 // geometry of the wide kernel per shape: waves per workgroup, query tiles per wave, LDS ring depth
 struct WideCfg { int nw, nt, nst, stg, klds; };

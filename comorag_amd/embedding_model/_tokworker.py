@@ -16,6 +16,9 @@ def init(tokenizer_json: str, direction: str = "right", strategy: str = "longest
     """direction / strategy: the in-process path's truncation settings (bge.py:_backend honours tokenizer.truncation_side) —
     a left-truncating tokenizer must yield the same ids from a worker process."""
     global _TOK
+    import os
+    if os.environ.get("CMR_TOKWORKER_RAYON"):          # probe knob (tools/tok_mode_probe.py): rayon threads of a worker's encode_batch
+        os.environ["RAYON_NUM_THREADS"] = os.environ["CMR_TOKWORKER_RAYON"]
     from tokenizers import Tokenizer
     _TOK = Tokenizer.from_str(tokenizer_json)
     _TOK.no_padding()
@@ -30,4 +33,5 @@ def ragged(prompts, max_length: int):
     if _LEN != int(max_length):          # configured once per length, not per call
         _TOK.enable_truncation(int(max_length), stride=0, strategy=_TRUNC["strategy"], direction=_TRUNC["direction"])
         _LEN = int(max_length)
-    return [np.asarray(e.ids, dtype=np.int32) for e in _TOK.encode_batch(list(prompts))]
+    enc = _TOK.encode_batch_fast(list(prompts)) if hasattr(_TOK, "encode_batch_fast") else _TOK.encode_batch(list(prompts))      # no offsets: ~5x
+    return [np.asarray(e.ids, dtype=np.int32) for e in enc]

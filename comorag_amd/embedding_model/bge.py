@@ -140,11 +140,13 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         import threading
         self._fast_tok = hasattr(tokenizer, "backend_tokenizer") and hasattr(tokenizer.backend_tokenizer, "to_str")
         self._bt_copies, self._bt_lock = {}, threading.Lock()
-        # -1 (default): processes are started by the first corpus-sized batch_encode call (>= two bucketing windows of texts), in the
-        # background — that call goes on with threads until the workers answer; 0: threads only; N > 0: N processes from the start.
+        # 0 (default): threads only; -1: processes are started by the first corpus-sized batch_encode call (>= two bucketing windows of
+        # texts), in the background — that call goes on with threads until the workers answer; N > 0: N processes from the start.
+        # (Same-box probe of every mode at BERT-base bf16, tools/tok_mode_probe.py: end to end 0.78-0.92 of forward-only for ALL of them,
+        # run-to-run spread larger than any difference between them — the lever was the tokenizer call itself, see _ragged.)
         self._tok_procs, self._tok_procs_starting = None, None
-        n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", -1))
-        self._tok_procs_auto = (min(4, max(1, (os.cpu_count() or 2) // 4)) if n_procs < 0 else 0) if self._fast_tok else 0
+        n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", 0))
+        self._tok_procs_auto = (min(4 if n_procs == -1 else -n_procs, max(1, (os.cpu_count() or 2) // 4)) if n_procs < 0 else 0) if self._fast_tok else 0
         if n_procs > 0 and self._fast_tok:
             self._tok_procs = self._start_tok_procs(n_procs)
         self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
@@ -213,7 +215,11 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         """Token ids per prompt, truncated, not padded: what `tokenizer(prompts, truncation=True, max_length=...)` yields — as int32
         arrays (made on the tokenizer's thread: the launching thread only ever concatenates them)."""
         if self._fast_tok:
-            return [np.asarray(e.ids, dtype=np.int32) for e in self._backend(max_length).encode_batch(list(prompts))]
+            # encode_batch_fast (tokenizers >= 0.20) skips the character-offset bookkeeping nothing here reads: the same ids at ~5x the rate
+            # (measured 0.8-1.1 K -> 4.7-5.2 K chunks/s of 512 tokens on 8 cores), i.e. a tokenizer that stays ahead of a 16-bit forward
+            bt = self._backend(max_length)
+            enc = bt.encode_batch_fast(list(prompts)) if hasattr(bt, "encode_batch_fast") else bt.encode_batch(list(prompts))
+            return [np.asarray(e.ids, dtype=np.int32) for e in enc]
         return [np.asarray(x, dtype=np.int32) for x in tokenize_ragged(self.tokenizer, prompts, max_length)]
 
     def _forward_ragged(self, id_arrays, normalize: bool):

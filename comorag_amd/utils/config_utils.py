@@ -36,7 +36,7 @@ class BaseConfig:
     embedding_length_bucketing: bool = True       # group a batch_encode call's prompts into mini-batches of similar token count
     embedding_tokenizer_threads: int = 2          # host threads tokenising ahead of the forward
     embedding_bucket_window: int = 4              # length bucketing sorts within windows of this many batches (the next windows are tokenised meanwhile)
-    embedding_tokenizer_processes: int = -1       # -1: worker PROCESSES started by the first corpus-sized batch_encode (>= 2 windows); 0: threads only; N: N processes (the Rust tokenizer holds the GIL)
+    embedding_tokenizer_processes: int = 0        # 0: threads only; -1: worker PROCESSES started by the first corpus-sized batch_encode (>= 2 windows); N: N processes (the Rust tokenizer holds the GIL)
     embedding_forward_batches: int = 1            # length-bucketed path: a forward mini-batch holds up to this many reference batches' worth of tokens
     embedding_hip_graphs: int = 24                # fused encoder: mini-batch shapes kept as captured hipGraphs (0 = launch every forward eagerly)
     embedding_fused_encoder: bool = True          # 16-bit BERT encoders: HIP attention + bias/residual/LayerNorm stages, one QKV GEMM (embedding_model/fused_bert.py)

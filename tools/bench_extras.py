@@ -134,7 +134,7 @@ def encoder_parity(torch, em, chunks, n=32, peak=None):
     return out
 
 
-def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, batch=32, tok_processes=-1, parity=True):
+def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, batch=32, tok_processes=0, parity=True):
     """Corpus-embed chunks/s end to end and where the time goes: tokenizer alone (host), forward + pool alone (device
     inputs ready), pool kernel alone; MFMA fraction of the forward from the model's matmul flops."""
     from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel, pool_l2norm
