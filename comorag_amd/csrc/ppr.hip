@@ -62,9 +62,19 @@ struct cmr_graph {
     long long* rowptr = nullptr;       // [nv + 1]
     int* col = nullptr;                // [ne]
     double* wnorm = nullptr;           // [ne]  w_ij / s_j of the SOURCE j of the pulled term (so y_i = sum_j wnorm * x_j)
-    int* dangling = nullptr;           // vertices with no incident weight
+    int* dangling = nullptr;           // vertices with no incident weight (internal ids, ascending)
     long long n_dangling = 0;
-    int* vertex_of_row = nullptr;      // passage row -> vertex
+    // Vertices are REORDERED at cmr_graph_create by degree class (the exported ids stay the caller's): internal order = rows of more
+    // than PPR_WAVE_DEG entries (a wave each), rows of PPR_ONE_DEG + 1 .. PPR_WAVE_DEG entries (eight lanes each), rows of <= PPR_ONE_DEG
+    // entries (ONE thread each, stored as 4-slot ELL records: one 16-byte column load + two 16-byte weight loads per thread).  A step then
+    // runs ~4x fewer waves than eight lanes for every row did — the step is latency x occupancy bound: waves in flight x ~4 dependent
+    // memory round trips each — and a hub vertex of thousands of edges is no longer a 1000-iteration tail on eight lanes.
+    long long n_wave = 0, n_oct = 0, n_one = 0;
+    int4* ell_col = nullptr;           // [n_one] columns of a short row (absent slots: column 0 with weight 0)
+    double* ell_w = nullptr;           // [n_one][4]
+    int* perm = nullptr;               // device: caller's vertex id -> internal vertex
+    std::vector<int> perm_h;           // the same on the host (seed vertices, the passage map)
+    int* vertex_of_row = nullptr;      // passage row -> INTERNAL vertex
     long long n_rows = 0;
     // Per-call scratch.  ComoRAG runs graph_search_with_fact_entities from up to 16 threads at once (ComoRAG.try_answer's
     // ThreadPoolExecutor, ComoRAG.py:437) and ctypes releases the GIL: every call takes its own set of vectors from this
@@ -167,29 +177,86 @@ __global__ __launch_bounds__(PPR_T) void ppr_dangling_kernel(const double* __res
 }
 
 // y_i = d * (sum_{j in N(i)} wnorm_ij * x_j + D * r_i) + (1 - d) * r_i
-// PPR_LPR lanes per vertex: ComoRAG's graphs mix passage vertices of degree ~3 with entity vertices of degree 10-30 and
-// more; with one thread per vertex a step lasted as long as the LONGEST row's chain of dependent loads (col -> x[col]):
-// 10 us per step at 6500 vertices, 197 us at 1.2 M (0.4 TB/s).  Eight lanes stride over a row's entries (coalesced col /
-// wnorm reads), each lane sums its entries in ascending order, the eight partials are combined by a fixed xor tree: one
-// summation order per row, reproducible bit for bit.
+// Three row classes in one launch (block ranges; see cmr_graph): a wave per long row, PPR_LPR lanes per medium row, a thread per
+// short row.  Every row has ONE summation order: lanes stride over a row's entries (coalesced col / wnorm reads) and sum theirs in
+// ascending order, the partials are combined by a fixed xor tree; a short row adds its four slots in slot order — reproducible bit
+// for bit.  (With one thread per vertex for every row a step lasted as long as the LONGEST row's chain of dependent loads; with
+// eight lanes for every row — round 2 — a 3-entry passage row left five lanes idle and the step ran 150 K waves at 1 M passages.)
 #define PPR_LPR 8
-__global__ __launch_bounds__(PPR_T) void ppr_step_kernel(const long long* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ wnorm,
-                                                         const double* __restrict__ x, const double* __restrict__ r, const double* __restrict__ dmass,
-                                                         double d, long long nv, double* __restrict__ y) {
-    const long long gt = (long long)blockIdx.x * PPR_T + threadIdx.x;
-    const long long i = gt / PPR_LPR;
-    const int sub = (int)(gt % PPR_LPR);
+#define PPR_ONE_DEG 4
+#define PPR_WAVE_DEG 256
+// A lane's share of a row: entries e0, e0 + STRIDE, ... < e1, summed in that order.  Four entries per round: their column / weight loads,
+// then their four gathers, are independent and in flight together — a lane's chain is (rowptr -> columns -> x) per ROUND, not per
+// entry (an entity row of 19 entries on eight lanes was three dependent col -> x round trips; now one).  An absent entry contributes
+// 0.0 * x[0]: adding +0.0 changes nothing, so the sum equals the one-entry-at-a-time loop bit for bit.
+template <int STRIDE>
+__device__ __forceinline__ double ppr_row_sum(long long e0, long long e1, const int* __restrict__ col, const double* __restrict__ wnorm,
+                                              const double* __restrict__ x) {
     double acc = 0.0;
-    if (i < nv) {
-        const long long e1 = rowptr[i + 1];
-        for (long long e = rowptr[i] + sub; e < e1; e += PPR_LPR) acc += wnorm[e] * x[col[e]];
-    }
+    for (long long e = e0; e < e1; e += 4 * STRIDE) {
+        int c[4];
+        double w[4], xv[4];
 #pragma unroll
-    for (int off = PPR_LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (i < nv && sub == 0) {
-        const double D = dmass ? dmass[0] : 0.0;
+        for (int u = 0; u < 4; ++u) {
+            const long long ee = e + (long long)u * STRIDE;
+            const bool ok = ee < e1;
+            c[u] = ok ? col[ee] : 0;
+            w[u] = ok ? wnorm[ee] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += w[u] * xv[u];
+    }
+    return acc;
+}
+__global__ __launch_bounds__(PPR_T) void ppr_step_kernel(const long long* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ wnorm,
+                                                         const int4* __restrict__ ell_col, const double* __restrict__ ell_w,
+                                                         const double* __restrict__ x, const double* __restrict__ r, const double* __restrict__ dmass,
+                                                         double d, long long n_wave, long long n_oct, long long n_one, unsigned b_wave, unsigned b_oct,
+                                                         double* __restrict__ y) {
+    const double D = dmass ? dmass[0] : 0.0;
+    if (blockIdx.x < b_wave) {                                   // a wave per row
+        const long long i = (long long)blockIdx.x * (PPR_T / 64) + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        double acc = 0.0;
+        if (i < n_wave) acc = ppr_row_sum<64>(rowptr[i] + lane, rowptr[i + 1], col, wnorm, x);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (i < n_wave && lane == 0) y[i] = d * (acc + D * r[i]) + (1.0 - d) * r[i];
+    } else if (blockIdx.x < b_wave + b_oct) {                    // eight lanes per row
+        const long long gt = (long long)(blockIdx.x - b_wave) * PPR_T + threadIdx.x;
+        const long long i = n_wave + gt / PPR_LPR;
+        const int sub = (int)(gt % PPR_LPR);
+        const bool in = i < n_wave + n_oct;
+        double acc = 0.0;
+        if (in) acc = ppr_row_sum<PPR_LPR>(rowptr[i] + sub, rowptr[i + 1], col, wnorm, x);
+#pragma unroll
+        for (int off = PPR_LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (in && sub == 0) y[i] = d * (acc + D * r[i]) + (1.0 - d) * r[i];
+    } else {                                                     // a thread per row: four ELL slots
+        const long long t = (long long)(blockIdx.x - b_wave - b_oct) * PPR_T + threadIdx.x;
+        if (t >= n_one) return;
+        const long long i = n_wave + n_oct + t;
+        const int4 c = ell_col[t];
+        const double2 w01 = reinterpret_cast<const double2*>(ell_w)[2 * t], w23 = reinterpret_cast<const double2*>(ell_w)[2 * t + 1];
+        const double x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];      // four independent gathers in flight
+        double acc = w01.x * x0;
+        acc += w01.y * x1;
+        acc += w23.x * x2;
+        acc += w23.y * x3;
         y[i] = d * (acc + D * r[i]) + (1.0 - d) * r[i];
     }
+}
+
+// caller's order <-> internal order
+__global__ __launch_bounds__(PPR_T) void ppr_permute_in_kernel(const double* __restrict__ src, const int* __restrict__ perm, long long nv, double* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i < nv) dst[perm[i]] = src[i];
+}
+__global__ __launch_bounds__(PPR_T) void ppr_permute_out_kernel(const double* __restrict__ src, const int* __restrict__ perm, long long nv, double* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * PPR_T + threadIdx.x;
+    if (i < nv) dst[i] = src[perm[i]];
 }
 
 __global__ __launch_bounds__(PPR_T) void ppr_gather_kernel(const double* __restrict__ x, const int* __restrict__ vertex_of_row, long long n, double* __restrict__ out) {
@@ -257,8 +324,10 @@ static void ppr_iterate_launches(cmr_graph* g, PprScratch* sc, double damping, i
     double *x = sc->x, *y = sc->y;
     for (int it = 0; it < iters; ++it) {
         if (g->n_dangling) hipLaunchKernelGGL(ppr_dangling_kernel, dim3(1), dim3(PPR_T), 0, s, x, g->dangling, g->n_dangling, sc->red + PPR_RED_BLOCKS);
-        hipLaunchKernelGGL(ppr_step_kernel, dim3(blocks_for(g->nv * PPR_LPR)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, x, sc->reset,
-                           g->n_dangling ? sc->red + PPR_RED_BLOCKS : nullptr, damping, g->nv, y);
+        const unsigned b_wave = g->n_wave ? (unsigned)((g->n_wave + PPR_T / 64 - 1) / (PPR_T / 64)) : 0u;
+        const unsigned b_oct = g->n_oct ? blocks_for(g->n_oct * PPR_LPR) : 0u, b_one = g->n_one ? blocks_for(g->n_one) : 0u;
+        hipLaunchKernelGGL(ppr_step_kernel, dim3(std::max(1u, b_wave + b_oct + b_one)), dim3(PPR_T), 0, s, g->rowptr, g->col, g->wnorm, g->ell_col, g->ell_w, x,
+                           sc->reset, g->n_dangling ? sc->red + PPR_RED_BLOCKS : nullptr, damping, g->n_wave, g->n_oct, g->n_one, b_wave, b_oct, y);
         std::swap(x, y);
     }
     *result = x;
@@ -347,40 +416,74 @@ int32_t cmr_graph_create(int32_t device_id, int64_t n_vertices, int64_t n_edges,
         strength[u] += w; deg[u + 1]++;
         if (u != v) { strength[v] += w; deg[v + 1]++; }
     }
+    // degree classes and the internal order: long rows, medium rows, short rows — each class in the caller's order
+    std::vector<int> perm((size_t)n_vertices);
+    long long n_wave = 0, n_oct = 0, n_one = 0;
+    for (int64_t i = 0; i < n_vertices; ++i) {
+        const long long dg = deg[i + 1];
+        if (dg > PPR_WAVE_DEG) ++n_wave; else if (dg > PPR_ONE_DEG) ++n_oct; else ++n_one;
+    }
+    {
+        long long at_w = 0, at_o = n_wave, at_1 = n_wave + n_oct;
+        for (int64_t i = 0; i < n_vertices; ++i) {
+            const long long dg = deg[i + 1];
+            perm[i] = (int)(dg > PPR_WAVE_DEG ? at_w++ : dg > PPR_ONE_DEG ? at_o++ : at_1++);
+        }
+    }
     for (int64_t i = 0; i < n_vertices; ++i) deg[i + 1] += deg[i];
     const long long ne = deg[n_vertices];
-    std::vector<std::pair<int, double>> ent((size_t)ne);
+    std::vector<std::pair<int, double>> ent((size_t)ne);          // (INTERNAL neighbour, weight) by the caller's row
     std::vector<long long> fill(deg.begin(), deg.end() - 1);
     for (int64_t e = 0; e < n_edges; ++e) {
         const int u = src[e], v = dst[e];
         const double w = weight ? weight[e] : 1.0;
-        ent[fill[u]++] = {v, w};
-        if (u != v) ent[fill[v]++] = {u, w};
+        ent[fill[u]++] = {perm[v], w};
+        if (u != v) ent[fill[v]++] = {perm[u], w};
     }
-    std::vector<int> col((size_t)ne);
-    std::vector<double> wn((size_t)ne);
+    std::vector<double> strength_int((size_t)n_vertices);
+    for (int64_t i = 0; i < n_vertices; ++i) strength_int[perm[i]] = strength[i];
+    // internal CSR of the long and medium rows, ELL records of the short ones; a row's entries in ascending INTERNAL neighbour order
+    // (stable: parallel edges keep their input order) — the one summation order of the row
+    const long long n_csr = n_wave + n_oct;
+    std::vector<long long> rowptr((size_t)n_csr + 1, 0);
+    for (int64_t i = 0; i < n_vertices; ++i)
+        if (perm[i] < n_csr) rowptr[perm[i] + 1] = deg[i + 1] - deg[i];
+    for (long long i = 0; i < n_csr; ++i) rowptr[i + 1] += rowptr[i];
+    std::vector<int> col((size_t)rowptr[n_csr]);
+    std::vector<double> wn((size_t)rowptr[n_csr]);
+    std::vector<int> ecol((size_t)n_one * 4, 0);
+    std::vector<double> ew((size_t)n_one * 4, 0.0);
     std::vector<int> dang;
     for (int64_t i = 0; i < n_vertices; ++i) {
         std::stable_sort(ent.begin() + deg[i], ent.begin() + deg[i + 1], [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
-        if (!(strength[i] > 0.0)) dang.push_back((int)i);
+        const int pi = perm[i];
         for (long long e = deg[i]; e < deg[i + 1]; ++e) {
             const int j = ent[e].first;
-            col[e] = j;
-            wn[e] = strength[j] > 0.0 ? ent[e].second / strength[j] : 0.0;      // mass leaving j along this edge
+            const double wv = strength_int[j] > 0.0 ? ent[e].second / strength_int[j] : 0.0;      // mass leaving j along this edge
+            if (pi < n_csr) { col[rowptr[pi] + (e - deg[i])] = j; wn[rowptr[pi] + (e - deg[i])] = wv; }
+            else { ecol[(size_t)(pi - n_csr) * 4 + (e - deg[i])] = j; ew[(size_t)(pi - n_csr) * 4 + (e - deg[i])] = wv; }
         }
     }
+    for (int64_t i = 0; i < n_vertices; ++i)
+        if (!(strength[i] > 0.0)) dang.push_back(perm[i]);
+    std::sort(dang.begin(), dang.end());
     cmr_graph* g = new cmr_graph();
     g->device = device_id; g->nv = n_vertices; g->ne = ne; g->n_dangling = (long long)dang.size();
+    g->n_wave = n_wave; g->n_oct = n_oct; g->n_one = n_one;
     auto up = [&](void** p, const void* h, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 8));
+        hipError_t e = hipMalloc(p, std::max<size_t>(bytes, 16));
         if (e != hipSuccess) return e;
         return bytes ? hipMemcpy(*p, h, bytes, hipMemcpyHostToDevice) : hipSuccess;
     };
-    hipError_t e = up((void**)&g->rowptr, deg.data(), (size_t)(n_vertices + 1) * 8);
-    if (e == hipSuccess) e = up((void**)&g->col, col.data(), (size_t)ne * 4);
-    if (e == hipSuccess) e = up((void**)&g->wnorm, wn.data(), (size_t)ne * 8);
+    hipError_t e = up((void**)&g->rowptr, rowptr.data(), (size_t)(n_csr + 1) * 8);
+    if (e == hipSuccess) e = up((void**)&g->col, col.data(), col.size() * 4);
+    if (e == hipSuccess) e = up((void**)&g->wnorm, wn.data(), wn.size() * 8);
+    if (e == hipSuccess) e = up((void**)&g->ell_col, ecol.data(), ecol.size() * 4);
+    if (e == hipSuccess) e = up((void**)&g->ell_w, ew.data(), ew.size() * 8);
     if (e == hipSuccess) e = up((void**)&g->dangling, dang.data(), dang.size() * 4);
+    if (e == hipSuccess) e = up((void**)&g->perm, perm.data(), perm.size() * 4);
     if (e != hipSuccess) { cmr_graph_destroy(g); return cmr_fail(e == hipErrorOutOfMemory ? CMR_ERR_OOM : CMR_ERR_HIP, "graph upload: %s", hipGetErrorString(e)); }
+    g->perm_h = std::move(perm);
     *out = g;
     return CMR_OK;
 }
@@ -389,7 +492,7 @@ int32_t cmr_graph_destroy(cmr_graph_t* g) {
     if (!g) return CMR_OK;
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
-    for (void* p : {(void*)g->rowptr, (void*)g->col, (void*)g->wnorm, (void*)g->dangling, (void*)g->vertex_of_row})
+    for (void* p : {(void*)g->rowptr, (void*)g->col, (void*)g->wnorm, (void*)g->dangling, (void*)g->vertex_of_row, (void*)g->ell_col, (void*)g->ell_w, (void*)g->perm})
         if (p) (void)hipFree(p);
     for (PprScratch* sc : g->pool) { sc->release(); delete sc; }
     delete g;
@@ -406,7 +509,11 @@ int32_t cmr_graph_set_passage_vertices(cmr_graph_t* g, const int32_t* vertex_of_
     if (g->vertex_of_row) PPR_TRY(hipFree(g->vertex_of_row));
     g->vertex_of_row = nullptr; g->n_rows = 0;
     PPR_TRY(hipMalloc((void**)&g->vertex_of_row, std::max<size_t>((size_t)n_rows * 4, 8)));
-    if (n_rows) PPR_TRY(hipMemcpy(g->vertex_of_row, vertex_of_row, (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    if (n_rows) {
+        std::vector<int> internal((size_t)n_rows);
+        for (int64_t i = 0; i < n_rows; ++i) internal[i] = g->perm_h[vertex_of_row[i]];
+        PPR_TRY(hipMemcpy(g->vertex_of_row, internal.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice));
+    }
     g->n_rows = n_rows;
     return CMR_OK;
 }
@@ -421,11 +528,16 @@ int32_t cmr_graph_ppr(cmr_graph_t* g, const double* reset, double damping, doubl
     if (!sc->own) PPR_TRY(hipStreamCreateWithFlags(&sc->own, hipStreamNonBlocking));
     hipStream_t s = sc->own;                                // concurrent callers do not queue behind each other on the null stream
     auto body = [&]() -> int {
-        PPR_TRY(hipMemcpyAsync(sc->reset, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, s));
+        // the caller's vertex order on both sides of the ABI, the internal (degree-class) order between them
+        PPR_TRY(hipMemcpyAsync(sc->x, reset, (size_t)g->nv * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(ppr_permute_in_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, sc->x, g->perm, g->nv, sc->reset);
         double* res = nullptr;
         int rc_ = ppr_iterate(g, sc, damping, tol, max_iter, s, iters, &res);
         if (rc_) return rc_;
-        PPR_TRY(hipMemcpyAsync(out_scores, res, (size_t)g->nv * 8, hipMemcpyDeviceToHost, s));
+        double* tmp = res == sc->x ? sc->y : sc->x;
+        hipLaunchKernelGGL(ppr_permute_out_kernel, dim3(blocks_for(g->nv)), dim3(PPR_T), 0, s, res, g->perm, g->nv, tmp);
+        PPR_TRY(hipGetLastError());
+        PPR_TRY(hipMemcpyAsync(out_scores, tmp, (size_t)g->nv * 8, hipMemcpyDeviceToHost, s));
         return CMR_OK;
     };
     rc = body();
@@ -444,6 +556,7 @@ int32_t cmr_index_ppr(cmr_index_t* idx, cmr_graph_t* g, const float* q_f32, cons
     std::vector<int> sv;
     std::vector<double> sw;
     merge_seeds(seed_vertices, seed_weights, n_seeds, sv, sw);
+    for (int& v : sv) v = g->perm_h[v];                     // distinct vertices after the merge: their order no longer matters
     const int ns = (int)sv.size();
     PprScratch* sc = nullptr;
     int rc = scratch_acquire(g, &sc);

@@ -263,3 +263,40 @@ def test_hooks_put_run_ppr_and_graph_search_on_the_device(golden_dir):
     np.testing.assert_allclose(sc2, np.sort(want2)[::-1], atol=2e-7 * want2.max())
     assert ids2[:10].tolist() == np.argsort(want2)[::-1][:10].tolist() and set(used) <= {"1", "5", "7", "9"}
     rag._hip["graph"].close()
+
+
+@pytest.mark.gpu
+def test_device_ppr_degree_classes_hub_medium_and_short_rows():
+    """cmr_graph_create reorders the vertices by degree class (a wave per row of > 256 entries, eight lanes per row of 5 .. 256, one
+    thread and a 4-slot ELL record per row of <= 4) and keeps the CALLER's vertex ids on both sides of the ABI.  A graph with two hubs
+    (1500 and 300 neighbours), a band of medium rows, a majority of rows with 1-4 entries (incl. exactly 4 and exactly 5), parallel
+    edges, a self-loop and isolated vertices — ids deliberately interleaved across the classes — against the oracle's dense solve."""
+    from comorag_amd.ppr import DeviceGraph, run_ppr
+    rng = np.random.default_rng(4242)
+    n = 2600
+    src, dst = [], []
+    hubs = (7, 1901)
+    for h, fan in zip(hubs, (1500, 300)):
+        nb = rng.choice(np.setdiff1d(np.arange(n), [h, 11, 12, 13]), fan, replace=False)
+        src += [h] * fan; dst += nb.tolist()
+    med = rng.choice(np.arange(20, n), 120, replace=False)                  # medium rows: 6 .. 40 extra neighbours each
+    for v in med:
+        nb = rng.choice(np.setdiff1d(np.arange(n), [v, 11, 12, 13]), int(rng.integers(6, 41)), replace=False)
+        src += [int(v)] * len(nb); dst += nb.tolist()
+    src += [5, 5, 5, 5, 6, 6, 6, 6, 6, 3, 3, 9]                              # vertex 5: exactly 4 more entries, vertex 6: 5, parallel edges 3-4 twice, self-loop 9-9
+    dst += [1, 2, 4, 8, 1, 2, 4, 8, 10, 4, 4, 9]
+    src, dst = np.array(src, np.int32), np.array(dst, np.int32)
+    w = rng.uniform(0.2, 2.0, len(src))
+    reset = np.where(rng.uniform(0, 1, n) < 0.05, rng.uniform(0, 1, n), 0.0)
+    reset[7] = 0.3; reset[11] = 0.4                                         # a seed on a hub and one on an isolated vertex (11, 12, 13 have no edges)
+    g = DeviceGraph(n, src, dst, w)
+    for d in (0.5, 0.85):
+        x = g.ppr(reset, damping=d, tol=1e-13)
+        want = ppr_np.personalized_pagerank(n, src, dst, w, reset, d)
+        np.testing.assert_allclose(x, want, atol=2e-11, rtol=0)
+        assert abs(x.sum() - 1.0) < 1e-9
+    idxs = [7, 1901, 5, 6, 11, 3, 9, 2599, 0]
+    a_ids, a_sc = run_ppr(g, reset, idxs)
+    b = np.array([ppr_np.personalized_pagerank(n, src, dst, w, reset, 0.5)[i] for i in idxs]); order = np.argsort(b)[::-1]
+    np.testing.assert_allclose(a_sc, b[order], atol=2e-11)
+    g.close()
