@@ -56,19 +56,32 @@ template <int DT> __device__ __forceinline__ void enc_unpack2(unsigned u, float&
 #define ATT_KSTR 72           // K rows in LDS: 64 elements + 8 of padding (144 B: ds_read_b128 of 16 consecutive rows hit 16 different 16-B slots)
 #define ATT_VSTR 68           // V^T rows in LDS: 64 keys + 4 (136 B: ds_read_b64 of 32 consecutive d rows hit 32 different bank pairs)
 #define ATT_NEG (-1.0e30f)
+#ifndef ATT_MIN_WG
+#define ATT_MIN_WG 2          // workgroups per CU the register budget is held to (__launch_bounds__)
+#endif
+#ifndef ATT_ABL
+#define ATT_ABL 0             // development ablations (wrong results): 1 no v_exp, 2 no QK^T MFMAs, 3 no PV MFMAs, 4 no K / V staging after chunk 0 and no barrier
+#endif
+#ifndef ATT_SKIP_RESCALE
+#define ATT_SKIP_RESCALE 0    // 1: a chunk that raises no query's running maximum (wave-uniform test) skips the 32 accumulator multiplies by 1.0 (measured SLOWER: 54 vs 50 us)
+#endif
 
 template <int DT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ lens, int L, int hidden,
+__global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ lens, int L, int hidden,
                                                            int n_heads, int n_qblocks, int total, float sc /* log2(e) / sqrt(64) */,
                                                            unsigned short* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned short k_lds[2][ATT_CHUNK * ATT_KSTR];
     __shared__ __attribute__((aligned(16))) unsigned short v_lds[2][64 * ATT_VSTR];
-    // workgroup id -> work item: consecutive items (the query blocks of one head, the heads of one sequence) stay on ONE XCD
-    // (hardware deals workgroup ids round-robin over the 8 XCDs), so a head's K / V come out of that XCD's L2 after the first block
-    const int per = (total + 7) >> 3;
-    const int item = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (item >= total) return;
-    const int qb = item % n_qblocks, head = (item / n_qblocks) % n_heads, seq = item / (n_qblocks * n_heads);
+    // workgroup id -> work item.  Hardware deals workgroup ids round-robin over the 8 XCDs: the query blocks of one (sequence, head)
+    // pair stay on ONE XCD, so the pair's K / V come out of that XCD's L2 after the first block; the PAIRS go round the XCDs, so every
+    // XCD holds a share of every sequence.  (Round 4 kept a whole sequence — all its heads — on one XCD: in a mini-batch of mixed
+    // lengths the XCD that drew the long sequences set the kernel's time — 32 sequences of 17 .. 512 tokens took as long as 32 of 512.)
+    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    const int pair = (j / n_qblocks) * 8 + xcd;
+    if (pair >= total / n_qblocks) return;
+    // (the host sorts a mini-batch's rows by ascending length: taking the sequences from the back starts the long ones first and
+    //  leaves the short ones to fill the tail)
+    const int qb = j % n_qblocks, head = pair % n_heads, seq = total / (n_qblocks * n_heads) - 1 - pair / n_heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c = lane & 31;
     const int q0 = qb * ATT_QBLOCK;
     int len = lens[seq];
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < nch) load_chunk(ch + 1);
+        if (ATT_ABL != 4 && ch + 1 < nch) load_chunk(ch + 1);
         // S^T tiles: keys t*32 + [0,32) of the chunk x the wave's 32 queries
         f32x16 s[2];
 #pragma unroll
@@ -144,8 +157,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
             for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const v4u kf = *reinterpret_cast<const v4u*>(&k_lds[cur][(t * 32 + c) * ATT_KSTR + ks * 16 + g * 8]);
-                s[t] = CmrBlk<DT>::mma(kf, qf[ks], s[t]);
+                const v4u kf = *reinterpret_cast<const v4u*>(&k_lds[ATT_ABL == 4 ? 0 : cur][(t * 32 + c) * ATT_KSTR + ks * 16 + g * 8]);
+                if (ATT_ABL != 2) s[t] = CmrBlk<DT>::mma(kf, qf[ks], s[t]);
+                else s[t][ks] += __uint_as_float(kf[0] & 0x3F800000u);
             }
         }
         const int k0 = ch * ATT_CHUNK;
@@ -170,14 +184,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -msc));
+                const float p = ATT_ABL == 1 ? fmaf(s[t][r], sc, -msc) : __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -msc));
                 s[t][r] = p;
                 ps += p;
             }
-        lsum = fmaf(lsum, alpha, ps);
-        m = mn;
+        // (after the first chunks the running maxima rarely move: alpha is exactly 1.0 in every lane then, and x * 1.0 == x)
+        if (!ATT_SKIP_RESCALE || __any(mn != m)) {
+            lsum = fmaf(lsum, alpha, ps);
+            m = mn;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        } else {
+            lsum += ps;
+        }
         // O^T += V^T P^T: four k-steps of 16 keys; the P registers 8*sp .. 8*sp + 7 of tile t are the B operand as they are
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -194,11 +213,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const unsigned short* 
                     const unsigned short* vrow = &v_lds[cur][(dt * 32 + c) * ATT_VSTR + kb];
                     const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
                     const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
-                    o[dt] = CmrBlk<DT>::mma(v4u{lo.x, lo.y, hi.x, hi.y}, pb, o[dt]);
+                    if (ATT_ABL != 3) o[dt] = CmrBlk<DT>::mma(v4u{lo.x, lo.y, hi.x, hi.y}, pb, o[dt]);
+                    else o[dt][0] += __uint_as_float((lo.x ^ pb[0]) & 0x3F800000u);
                 }
             }
-        if (ch + 1 < nch) store_chunk(cur ^ 1);
-        __syncthreads();
+        if (ATT_ABL != 4) {
+            if (ch + 1 < nch) store_chunk(cur ^ 1);
+            __syncthreads();
+        }
     }
     const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
     if (qrow < L) {
@@ -219,7 +241,8 @@ hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int
     const int n_qblocks = (L + ATT_QBLOCK - 1) / ATT_QBLOCK;
     const long long total = (long long)n_qblocks * n_heads * b;
     if (total > (1LL << 28)) return hipErrorInvalidValue;
-    const int per = (int)((total + 7) / 8);
+    const long long pairs = (long long)n_heads * b;
+    const int per = (int)((pairs + 7) / 8) * n_qblocks;        // workgroups per XCD: its share of the (sequence, head) pairs x their query blocks
     const float sc = 1.4426950408889634f * 0.125f;
     const dim3 grid((unsigned)(per * 8)), block(256);
     if (dtype == CMR_DT_BF16)
