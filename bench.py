@@ -752,7 +752,7 @@ def main():
         else:
             out["roofline"]["traffic_error"] = tr["error"][:110]
     if out["roofline"]["traffic"] is None:
-        for prof_file in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json"):
+        for prof_file in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json"):
             prof_file = os.path.join(ROOT, "profiles", prof_file)
             if os.path.exists(prof_file):
                 pj = json.load(open(prof_file))

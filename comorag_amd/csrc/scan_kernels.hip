@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
     constexpr int STG = NW == 8 ? WIDE8_STG : WIDE_STG;         // staging records per wave (LDS budget)
     static_assert(NW == 4 || (NW == 8 && NT == 1), "8 waves hold one tile each");
     static_assert(NW == 4 || (size_t)STG * 16 <= (size_t)(CAP + 2) * 8, "8-wave kernel: the staging records live in the compaction stage");
-    static_assert(KS % GRP == 0 && GRP % NW == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && NST >= 4, "group geometry");
+    static_assert(KS % GRP == 0 && GRP % NW == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && NST >= 3, "group geometry");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -3,7 +3,7 @@ tools/rocpd_pmc.py) into the two PMC files under profiles/:
     python tools/summarise_profiles.py gpurun_out/r2_profiles  ->  <dir>/r2_pmc_hbm_traffic.json, <dir>/r2_pmc_wide.json
 HBM bytes follow MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count kilobytes; gfx950 tallies 128-B fetch requests at 64 B, hence FETCH x 2."""
 import json, os, sys
-ROUND = os.environ.get("ROUND", "r4")
+ROUND = os.environ.get("ROUND", "r5")
 
 d = sys.argv[1]
 
@@ -70,6 +70,11 @@ if raw and kernel_us:
                                    "issue_stalled (SQ_WAIT_INST_ANY)": raw.get("SQ_WAIT_INST_ANY", 0.0) / wave_cycles if wave_cycles else None,
                                    "issuing (SQ_ACTIVE_INST_ANY)": raw.get("SQ_ACTIVE_INST_ANY", 0.0) / wave_cycles if wave_cycles else None},
                "valu_per_mfma": raw.get("SQ_INSTS_VALU", 0.0) / mfma if mfma else None,
+               # SQ_INSTS_VALU counts the MFMAs themselves (VALU-class instructions): round 4's 1.95 was 1.00 MFMA + 0.95 others, which is
+               # what the kernel's listing holds (96 MFMAs + 68 VALU on the hot path of a panel + the slow path)
+               "valu_non_mfma_per_mfma": raw.get("SQ_INSTS_VALU", 0.0) / mfma - 1.0 if mfma else None,
+               "non_mfma_instructions_per_mfma": (raw.get("SQ_INSTS_VALU", 0.0) - mfma + raw.get("SQ_INSTS_SALU", 0.0) + raw.get("SQ_INSTS_LDS", 0.0)
+                                                  + raw.get("SQ_INSTS_VMEM", 0.0)) / mfma if mfma else None,
                "salu_per_mfma": raw.get("SQ_INSTS_SALU", 0.0) / mfma if mfma else None,
                "lds_instr_per_mfma": raw.get("SQ_INSTS_LDS", 0.0) / mfma if mfma else None,
                "vmem_instr_per_mfma": raw.get("SQ_INSTS_VMEM", 0.0) / mfma if mfma else None,
