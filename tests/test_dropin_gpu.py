@@ -233,10 +233,18 @@ def test_encoder_end_to_end_vs_oracle():
     np.testing.assert_allclose(em2.batch_encode(texts), got, atol=2e-5)
     # bucketing within windows of ONE reference chunk (three windows here, the next ones tokenised while one is on the GPU),
     # and the same with the tokenizer in worker processes: same rows, same order
-    for extra in ({"embedding_bucket_window": 1}, {"embedding_bucket_window": 2, "embedding_tokenizer_processes": 2}):
+    # ... and with worker processes started lazily by the first corpus-sized call (-1: the call that starts them goes on with threads,
+    # the next one finds them answering)
+    for extra in ({"embedding_bucket_window": 1}, {"embedding_bucket_window": 2, "embedding_tokenizer_processes": 2},
+                  {"embedding_bucket_window": 1, "embedding_tokenizer_processes": -1}):
         cfg3 = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=4, embedding_max_seq_len=2048, **extra)
         em3 = cls(global_config=cfg3, embedding_model_name=cfg3.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
         np.testing.assert_allclose(em3.batch_encode(texts), got, atol=2e-5)
+        if extra.get("embedding_tokenizer_processes") == -1 and len(texts) >= 2 * 4:
+            assert em3._tok_procs_starting is not None                  # two windows of texts: the start was triggered
+            em3._tok_procs_starting.join(120.0)
+            assert em3._tok_procs is not None
+            np.testing.assert_allclose(em3.batch_encode(texts), got, atol=2e-5)      # now through the worker processes
         em3.close()
 
 

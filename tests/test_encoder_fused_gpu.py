@@ -164,6 +164,42 @@ def test_fused_layer_stack_vs_transformers_forward_and_oracle(dtype):
         e.close()
 
 
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_gelu_in_the_gemm_epilogue_vs_the_exact_kernel_vs_oracle(dtype):
+    """`embedding_gelu = "epilogue"` (default): FFN-up GEMM + bias + GELU as ONE hipBLASLt launch, GELU in its tanh form;
+    `"exact"`: the GEMM, then PyTorch's erf-form kernel (what transformers runs).  Both stacks are held to the SAME bar against the fp32
+    oracle (erf form, BGEEmbedding.py:119), and to each other within the 16-bit rounding of the activations they differ in."""
+    import torch
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.embedding_model.fused_bert import gelu_epilogue_available
+    from comorag_amd.utils.config_utils import BaseConfig
+    from oracle import encode_torch as enc
+    model, tok = _peaked_tiny_bert(getattr(torch, dtype))
+    with torch.no_grad():
+        for lyr in model.encoder.layer:                 # pre-activations of a few units: where the two GELU forms differ most (|x| ~ 2.7)
+            lyr.intermediate.dense.weight.mul_(6.0)
+        model.to(getattr(torch, dtype)).float()
+    texts = [f"the prince and the golden slipper number {i} " + "and the bird in the tree " * (i % 7) for i in range(19)] + ["midnight"]
+    want = enc.batch_encode(model, tok, texts, batch_size=8, max_length=128)
+    cls = _get_embedding_model_class("bge-tiny-random")
+    out = {}
+    for mode in ("epilogue", "exact"):
+        cfg = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=8, embedding_max_seq_len=128, embedding_model_dtype=dtype, embedding_gelu=mode)
+        em = cls(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+        assert em.encoder_path == "hip-fused-layers"
+        out[mode] = (em.batch_encode(texts), em._fused.gelu_path)
+        em.close()
+    assert out["exact"][1] == "exact-erf-kernel"
+    assert out["epilogue"][1] == ("hipblaslt-epilogue-tanh" if gelu_epilogue_available(torch.device("cuda", 0), getattr(torch, dtype)) else "exact-erf-kernel")
+    tol = {"bfloat16": 6e-3, "float16": 1e-3}[dtype]
+    for mode in out:
+        got = out[mode][0]
+        np.testing.assert_allclose(got, want, atol=tol)
+        assert float(np.min((got * want).sum(1))) > 0.999          # north_star: cosine within 1e-3 of the reference path
+        assert np.abs(got @ got.T - want @ want.T).max() < 1e-3     # every pairwise score within 1e-3
+    assert np.abs(out["epilogue"][0] - out["exact"][0]).max() <= tol
+
+
 def test_models_the_fused_stack_declines_keep_the_transformers_forward():
     import torch
     from comorag_amd.embedding_model import _get_embedding_model_class
