@@ -54,13 +54,24 @@ template <int DT> __device__ __forceinline__ void enc_unpack2(unsigned u, float&
 #define ATT_CHUNK 64          // keys per LDS chunk
 #define ATT_QBLOCK 128        // query rows per workgroup (4 waves x 32)
 #define ATT_KSTR 72           // K rows in LDS: 64 elements + 8 of padding (144 B: ds_read_b128 of 16 consecutive rows hit 16 different 16-B slots)
+#ifndef ATT_VTR
+#define ATT_VTR 1             // 1: V goes into LDS ROW-MAJOR (two 16-byte writes per thread, as K) and the PV step reads its A operands with
+#endif                        //    ds_read_b64_tr_b16 (gfx950's transposing LDS read); 0: V transposed on its way in (eight 4-byte writes per thread)
+#if ATT_VTR && defined(ATT_VSTR_OVERRIDE)
+#define ATT_VSTR ATT_VSTR_OVERRIDE
+#elif ATT_VTR
+#define ATT_VSTR 88           // V rows in LDS: 64 d + 24 of padding (176 B).  Measured, us per layer at 32 x 512 x 12 heads bf16 / 16 heads fp16 (gpurun_out/r5x):
+                              // 72: 46.8 / 59.7   80: 48.3 / 61.8   88: 46.2 / 59.6   96: 47.4 / 60.9   104: 48.7 / 63.7   112: 49.0 / 62.1   136: 48.5 / 62.3
+#else
 #define ATT_VSTR 68           // V^T rows in LDS: 64 keys + 4 (136 B: ds_read_b64 of 32 consecutive d rows hit 32 different bank pairs)
+#endif
+typedef short att_v4s __attribute__((ext_vector_type(4)));
 #define ATT_NEG (-1.0e30f)
 #ifndef ATT_MIN_WG
 #define ATT_MIN_WG 2          // workgroups per CU the register budget is held to (__launch_bounds__)
 #endif
 #ifndef ATT_ABL
-#define ATT_ABL 0             // development ablations (wrong results): 1 no v_exp, 2 no QK^T MFMAs, 3 no PV MFMAs, 4 no K / V staging after chunk 0 and no barrier
+#define ATT_ABL 0             // development ablations (wrong results): 1 no v_exp, 2 no QK^T MFMAs, 3 no PV MFMAs, 4 no K / V staging after chunk 0 and no barrier, 5 no barrier, 6 no V^T stores, 7 no K / V global loads
 #endif
 #ifndef ATT_SKIP_RESCALE
 #define ATT_SKIP_RESCALE 0    // 1: a chunk that raises no query's running maximum (wave-uniform test) skips the 32 accumulator multiplies by 1.0 (measured SLOWER: 54 vs 50 us)
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
                                                            int n_heads, int n_qblocks, int total, float sc /* log2(e) / sqrt(64) */,
                                                            unsigned short* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned short k_lds[2][ATT_CHUNK * ATT_KSTR];
-    __shared__ __attribute__((aligned(16))) unsigned short v_lds[2][64 * ATT_VSTR];
+    __shared__ __attribute__((aligned(16))) unsigned short v_lds[2][64 * ATT_VSTR];      // ATT_VTR: [key][d], else [d][key]
     // workgroup id -> work item.  Hardware deals workgroup ids round-robin over the 8 XCDs: the query blocks of one (sequence, head)
     // pair stay on ONE XCD, so the pair's K / V come out of that XCD's L2 after the first block; the PAIRS go round the XCDs, so every
     // XCD holds a share of every sequence.  (Round 4 kept a whole sequence — all its heads — on one XCD: in a mini-batch of mixed
@@ -122,20 +133,25 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
             const int key = k0 + kr + 32 * h;
             kreg[h] = v4u{0, 0, 0, 0};
             if (key < len) kreg[h] = *reinterpret_cast<const v4u*>(kbase + (size_t)key * rs + kseg * 8);
-            const int vkey = k0 + 2 * pi + h;
+            const int vkey = ATT_VTR ? key : k0 + 2 * pi + h;                  // ATT_VTR: the same (row, segment) as K
             vreg[h] = v4u{0, 0, 0, 0};
-            if (vkey < len) vreg[h] = *reinterpret_cast<const v4u*>(vbase + (size_t)vkey * rs + dseg * 8);
+            if (vkey < len) vreg[h] = *reinterpret_cast<const v4u*>(vbase + (size_t)vkey * rs + (ATT_VTR ? kseg : dseg) * 8);
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + 32 * h) * ATT_KSTR + kseg * 8]) = kreg[h];
+#if ATT_VTR
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {                  // element 2w and 2w + 1 of both keys -> V^T[d][key0], V^T[d][key0 + 1]
+        for (int h = 0; h < (ATT_ABL == 6 ? 0 : 2); ++h) *reinterpret_cast<v4u*>(&v_lds[buf][(kr + 32 * h) * ATT_VSTR + kseg * 8]) = vreg[h];
+#else
+#pragma unroll
+        for (int w = 0; w < (ATT_ABL == 6 ? 0 : 4); ++w) {                  // element 2w and 2w + 1 of both keys -> V^T[d][key0], V^T[d][key0 + 1]
             const unsigned a = vreg[0][w], b = vreg[1][w];
             *reinterpret_cast<unsigned*>(&v_lds[buf][(dseg * 8 + 2 * w) * ATT_VSTR + 2 * pi]) = (a & 0xFFFFu) | (b << 16);
             *reinterpret_cast<unsigned*>(&v_lds[buf][(dseg * 8 + 2 * w + 1) * ATT_VSTR + 2 * pi]) = (a >> 16) | (b & 0xFFFF0000u);
         }
+#endif
     };
 
     f32x16 o[2];
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
         const int cur = ch & 1;
-        if (ATT_ABL != 4 && ch + 1 < nch) load_chunk(ch + 1);
+        if (ATT_ABL != 4 && ATT_ABL != 7 && ch + 1 < nch) load_chunk(ch + 1);
         // S^T tiles: keys t*32 + [0,32) of the chunk x the wave's 32 queries
         f32x16 s[2];
 #pragma unroll
@@ -210,16 +226,27 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
                 const int kb = t * 32 + sp * 16 + 4 * g;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
+#if ATT_VTR
+                    // the A operand of lane l: V[kb + {0..3, 8..11}][dt*32 + c].  A transposing read hands lane i of a 16-lane group column i of the
+                    // 4 x 16 block whose row (i >> 2), columns 4 * (i & 3) .. + 3 that lane addresses (tools/probe/tr_probe.hip): rows = keys
+                    // kb .. kb + 3, columns = d of this group's sixteen lanes
+                    const unsigned short* vblk = &v_lds[cur][(kb + ((lane & 15) >> 2)) * ATT_VSTR + dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
+                    typedef __attribute__((address_space(3))) att_v4s* lds_v4s;
+                    const att_v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)vblk);
+                    const att_v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(vblk + 8 * ATT_VSTR));
+                    const uint2 lo = __builtin_bit_cast(uint2, lo4), hi = __builtin_bit_cast(uint2, hi4);
+#else
                     const unsigned short* vrow = &v_lds[cur][(dt * 32 + c) * ATT_VSTR + kb];
                     const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
                     const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
+#endif
                     if (ATT_ABL != 3) o[dt] = CmrBlk<DT>::mma(v4u{lo.x, lo.y, hi.x, hi.y}, pb, o[dt]);
                     else o[dt][0] += __uint_as_float((lo.x ^ pb[0]) & 0x3F800000u);
                 }
             }
         if (ATT_ABL != 4) {
             if (ch + 1 < nch) store_chunk(cur ^ 1);
-            __syncthreads();
+            if (ATT_ABL != 5) __syncthreads();
         }
     }
     const float inv = 1.0f / (lsum + __shfl_xor(lsum, 32));
