@@ -200,6 +200,28 @@ def test_gelu_in_the_gemm_epilogue_vs_the_exact_kernel_vs_oracle(dtype):
     assert np.abs(out["epilogue"][0] - out["exact"][0]).max() <= tol
 
 
+def test_fused_forward_launches_no_gelu_kernel():
+    """With the epilogue path the encoder's forward holds NO GELU launch of its own (the activation is inside the FFN-up GEMM): the kernel
+    list of one fused forward, taken with torch's profiler, names no Gelu kernel — the exact path's list does."""
+    import torch
+    from torch.profiler import ProfilerActivity, profile
+    from comorag_amd.embedding_model.fused_bert import FusedBertLayers
+    model, _ = _peaked_tiny_bert(torch.bfloat16)
+    model = model.to("cuda", dtype=torch.bfloat16).eval()
+    ids = torch.randint(0, model.config.vocab_size, (4, 64), device="cuda")
+    lens = np.array([64, 40, 17, 64], np.int32)
+    names = {}
+    for mode in ("epilogue", "exact"):
+        fz = FusedBertLayers(model, gelu=mode)
+        fz(ids, lens, pool=True); torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fz(ids, lens, pool=True); torch.cuda.synchronize()
+        names[mode] = (fz.gelu_path, [e.key for e in prof.key_averages()])
+    assert names["exact"][0] == "exact-erf-kernel" and any("elu" in n for n in names["exact"][1]), names["exact"][1]
+    if names["epilogue"][0] == "hipblaslt-epilogue-tanh":
+        assert not any("Gelu" in n or "gelu" in n for n in names["epilogue"][1]), names["epilogue"][1]
+
+
 def test_models_the_fused_stack_declines_keep_the_transformers_forward():
     import torch
     from comorag_amd.embedding_model import _get_embedding_model_class
