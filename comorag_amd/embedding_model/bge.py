@@ -179,8 +179,12 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                 self._tok_procs = self._start_tok_procs(self._tok_procs_auto)
             except Exception:                     # no worker processes on this host: the threads stay
                 self._tok_procs_auto = 0
-        self._tok_procs_starting = threading.Thread(target=_go, name="cmr-tok-procs", daemon=True)
-        self._tok_procs_starting.start()
+        with self._bt_lock:                  # ComoRAG encodes from up to 16 threads over one model instance: ONE of them starts the workers
+            if self._tok_procs_starting is not None:
+                return
+            t = threading.Thread(target=_go, name="cmr-tok-procs", daemon=True)
+            t.start()
+            self._tok_procs_starting = t
 
     def _init_embedding_config(self) -> None:
         self.embedding_config = EmbeddingConfig.from_dict({
