@@ -52,7 +52,7 @@ template <int DT> __device__ __forceinline__ void enc_unpack2(unsigned u, float&
 
 // ------------------------------------------------------------------------------------------------ attention
 #define ATT_CHUNK 64          // keys per LDS chunk
-#define ATT_QBLOCK 128        // query rows per workgroup (4 waves x 32)
+#define ATT_QBLOCK 128        // query rows per workgroup of the 4-wave kernel (4 waves x 32); the 8-wave kernel takes 256
 #define ATT_KSTR 72           // K rows in LDS: 64 elements + 8 of padding (144 B: ds_read_b128 of 16 consecutive rows hit 16 different 16-B slots)
 #ifndef ATT_VTR
 #define ATT_VTR 1             // 1: V goes into LDS ROW-MAJOR (two 16-byte writes per thread, as K) and the PV step reads its A operands with
@@ -77,8 +77,12 @@ typedef short att_v4s __attribute__((ext_vector_type(4)));
 #define ATT_SKIP_RESCALE 0    // 1: a chunk that raises no query's running maximum (wave-uniform test) skips the 32 accumulator multiplies by 1.0 (measured SLOWER: 54 vs 50 us)
 #endif
 
-template <int DT>
-__global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ lens, int L, int hidden,
+// NW = waves per workgroup.  4: 128 query rows share a staged K / V chunk.  8: 256 rows do — the chunk's staging (global -> registers
+// -> LDS, one barrier) is the longest leg of this kernel (26 % at 4 waves: DESIGN 4.10) and costs the same per chunk however many
+// query rows consume it; every thread then stages ONE 16-byte segment of K and of V instead of two.  Used for sequences of >= 256
+// (padded) tokens; shorter mini-batches keep 4 waves (half of an 8-wave workgroup would hold padding rows only).
+template <int DT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ lens, int L, int hidden,
                                                            int n_heads, int n_qblocks, int total, float sc /* log2(e) / sqrt(64) */,
                                                            unsigned short* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned short k_lds[2][ATT_CHUNK * ATT_KSTR];
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
     //  leaves the short ones to fill the tail)
     const int qb = j % n_qblocks, head = pair % n_heads, seq = total / (n_qblocks * n_heads) - 1 - pair / n_heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, c = lane & 31;
-    const int q0 = qb * ATT_QBLOCK;
+    constexpr int QBLOCK = NW * 32, PASSES = 8 / NW, PROWS = NW * 8;      // rows per workgroup; staging passes of PROWS K / V rows each
+    const int q0 = qb * QBLOCK;
     int len = lens[seq];
     len = len < L ? len : L;
     const size_t rs = (size_t)3 * hidden;
@@ -125,12 +130,12 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
     // chunk staging.  K: thread -> rows r and r + 32, 16-byte segment seg.  V: thread -> the key pair pi, d segment dseg.
     const int kr = tid >> 3, kseg = tid & 7;
     const int pi = wave * 8 + (lane & 7), dseg = lane >> 3;
-    v4u kreg[2], vreg[2];
+    v4u kreg[PASSES], vreg[PASSES];
     auto load_chunk = [&](int ch) {
         const int k0 = ch * ATT_CHUNK;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int key = k0 + kr + 32 * h;
+        for (int h = 0; h < PASSES; ++h) {
+            const int key = k0 + kr + PROWS * h;
             kreg[h] = v4u{0, 0, 0, 0};
             if (key < len) kreg[h] = *reinterpret_cast<const v4u*>(kbase + (size_t)key * rs + kseg * 8);
             const int vkey = ATT_VTR ? key : k0 + 2 * pi + h;                  // ATT_VTR: the same (row, segment) as K
@@ -140,10 +145,10 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + 32 * h) * ATT_KSTR + kseg * 8]) = kreg[h];
+        for (int h = 0; h < PASSES; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + PROWS * h) * ATT_KSTR + kseg * 8]) = kreg[h];
 #if ATT_VTR
 #pragma unroll
-        for (int h = 0; h < (ATT_ABL == 6 ? 0 : 2); ++h) *reinterpret_cast<v4u*>(&v_lds[buf][(kr + 32 * h) * ATT_VSTR + kseg * 8]) = vreg[h];
+        for (int h = 0; h < (ATT_ABL == 6 ? 0 : PASSES); ++h) *reinterpret_cast<v4u*>(&v_lds[buf][(kr + PROWS * h) * ATT_VSTR + kseg * 8]) = vreg[h];
 #else
 #pragma unroll
         for (int w = 0; w < (ATT_ABL == 6 ? 0 : 4); ++w) {                  // element 2w and 2w + 1 of both keys -> V^T[d][key0], V^T[d][key0 + 1]
@@ -263,22 +268,28 @@ __global__ __launch_bounds__(256, ATT_MIN_WG) void attn_fwd_kernel(const unsigne
     }
 }
 
-hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int b, int L, int n_heads, void* out, hipStream_t s) {
+#ifndef ATT_WAVES_MODE
+#define ATT_WAVES_MODE 0      // 0: eight waves per workgroup for mini-batches of >= 256 (padded) tokens, four below; 4 / 8: always
+#endif
+template <int DT, int NW>
+static hipError_t launch_attention(const void* qkv, const int* lens, int b, int L, int n_heads, void* out, hipStream_t s) {
+    static_assert(ATT_VTR || NW == 4, "the transposed-store layout of V is a 4-wave mapping");
     const int hidden = n_heads * 64;
-    const int n_qblocks = (L + ATT_QBLOCK - 1) / ATT_QBLOCK;
+    const int n_qblocks = (L + NW * 32 - 1) / (NW * 32);
     const long long total = (long long)n_qblocks * n_heads * b;
     if (total > (1LL << 28)) return hipErrorInvalidValue;
     const long long pairs = (long long)n_heads * b;
     const int per = (int)((pairs + 7) / 8) * n_qblocks;        // workgroups per XCD: its share of the (sequence, head) pairs x their query blocks
     const float sc = 1.4426950408889634f * 0.125f;
-    const dim3 grid((unsigned)(per * 8)), block(256);
-    if (dtype == CMR_DT_BF16)
-        hipLaunchKernelGGL(attn_fwd_kernel<CMR_DT_BF16>, grid, block, 0, s, reinterpret_cast<const unsigned short*>(qkv), lens, L, hidden, n_heads,
-                           n_qblocks, (int)total, sc, reinterpret_cast<unsigned short*>(out));
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel<CMR_DT_F16>, grid, block, 0, s, reinterpret_cast<const unsigned short*>(qkv), lens, L, hidden, n_heads,
-                           n_qblocks, (int)total, sc, reinterpret_cast<unsigned short*>(out));
+    hipLaunchKernelGGL((attn_fwd_kernel<DT, NW>), dim3((unsigned)(per * 8)), dim3(NW * 64), 0, s, reinterpret_cast<const unsigned short*>(qkv), lens, L, hidden,
+                       n_heads, n_qblocks, (int)total, sc, reinterpret_cast<unsigned short*>(out));
     return hipGetLastError();
+}
+
+hipError_t cmr_launch_attention(const void* qkv, int dtype, const int* lens, int b, int L, int n_heads, void* out, hipStream_t s) {
+    const bool eight = ATT_VTR && (ATT_WAVES_MODE == 8 || (ATT_WAVES_MODE == 0 && L >= 256));
+    if (dtype == CMR_DT_BF16) return eight ? launch_attention<CMR_DT_BF16, (ATT_VTR ? 8 : 4)>(qkv, lens, b, L, n_heads, out, s) : launch_attention<CMR_DT_BF16, 4>(qkv, lens, b, L, n_heads, out, s);
+    return eight ? launch_attention<CMR_DT_F16, (ATT_VTR ? 8 : 4)>(qkv, lens, b, L, n_heads, out, s) : launch_attention<CMR_DT_F16, 4>(qkv, lens, b, L, n_heads, out, s);
 }
 
 // ------------------------------------------------------------------------------------------------ bias + residual + LayerNorm
