@@ -894,7 +894,9 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
 #endif
 constexpr int wide_group(int ks, int nw) { return (nw == 4 && ks % WIDE_GROUP3 == 0) ? WIDE_GROUP3 : WIDE_GROUP; }
 constexpr int wide_nst4(int ks) { return ks % WIDE_GROUP3 == 0 ? WIDE4_NST3 : WIDE4_NST; }
+#ifndef WIDE_ADEPTH
 #define WIDE_ADEPTH 8     // LDS read-ahead ring of a wave, in blocks (two quads: one in use, one landing)
+#endif
 
 // Epilogue pieces of the wide kernel.  The wave's register file is full of query fragments, and hipcc's allocator
 // spills the values with the longest live range first — the fragments — whenever ANY block of the loop needs more
@@ -1156,7 +1158,7 @@ __device__ __forceinline__ void wide_compact(u64 need, int k, u64& tau_key, floa
 // the LDS's 256 B/clk ds_read_b128 rate at full MFMA rate, guide §LDS) and a 4-block read-ahead ring instead of 8.
 template <int DT, int KS, int NT, int CAP, int NSTG, int KLDS, int ABL = 0, int NW = WIDE_WAVES>
 __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
-    constexpr int GRP = wide_group(KS, NW), NST = NSTG, ADEPTH = NW == 8 ? 4 : WIDE_ADEPTH;
+    constexpr int GRP = wide_group(KS, NW), NST = NSTG, ADEPTH = NW == 8 ? 4 : (wide_group(KS, NW) % WIDE_ADEPTH == 0 ? WIDE_ADEPTH : 8);
     constexpr int STG = NW == 8 ? WIDE8_STG : WIDE_STG;         // staging records per wave (LDS budget)
     static_assert(NW == 4 || (NW == 8 && NT == 1), "8 waves hold one tile each");
     static_assert(NW == 4 || (size_t)STG * 16 <= (size_t)(CAP + 2) * 8, "8-wave kernel: the staging records live in the compaction stage");
