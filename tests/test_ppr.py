@@ -300,3 +300,26 @@ def test_device_ppr_degree_classes_hub_medium_and_short_rows():
     b = np.array([ppr_np.personalized_pagerank(n, src, dst, w, reset, 0.5)[i] for i in idxs]); order = np.argsort(b)[::-1]
     np.testing.assert_allclose(a_sc, b[order], atol=2e-11)
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["all_medium", "all_short", "one_hub_only"])
+def test_device_ppr_with_an_empty_degree_class(kind):
+    """Graphs in which a degree class of the internal layout is EMPTY: a complete graph on 12 vertices (every row has 11 entries: no
+    short rows, no ELL records), a ring (every row has 2: no CSR rows at all), a star of 400 leaves (one wave row, 400 one-entry rows,
+    no medium rows)."""
+    from comorag_amd.ppr import DeviceGraph
+    if kind == "all_medium":
+        n = 12; src, dst = np.array([(i, j) for i in range(n) for j in range(i + 1, n)], np.int32).T
+    elif kind == "all_short":
+        n = 40; src = np.arange(n, dtype=np.int32); dst = ((src + 1) % n).astype(np.int32)
+    else:
+        n = 401; src = np.zeros(400, np.int32); dst = np.arange(1, 401, dtype=np.int32)
+    rng = np.random.default_rng(len(src))
+    w = rng.uniform(0.5, 1.5, len(src))
+    reset = rng.uniform(0, 1, n); reset[n // 2] = 0.0
+    g = DeviceGraph(n, np.ascontiguousarray(src), np.ascontiguousarray(dst), w)
+    x = g.ppr(reset, damping=0.5)
+    want = ppr_np.personalized_pagerank(n, src, dst, w, reset, 0.5)
+    np.testing.assert_allclose(x, want, atol=1e-10, rtol=0)
+    g.close()
