@@ -816,21 +816,6 @@ def main():
                                        "basis": "step time of ONE 1.25 M-row shard measured on this GPU vs the 10 M-row step above; the exchange (10-40 KiB per rank) "
                                                 "runs on the post stream under the next scan and is not included",
                                        "batch64_speedup": head["ms_per_step"] / s64["ms_per_step"], "batch256_speedup": c3["ms_per_step"] / s256["ms_per_step"]}
-        if not args.no_cpu_baseline:
-            if host is None:                    # not enough host RAM for the full fp32 copy: first 1 M rows, scaled
-                n1 = min(args.rows, 1_000_000)
-                host = np.empty((n1, args.dim), dtype=np.float32)
-                at = 0
-                for blk in gen_rows_dev(torch, 0, n1, args.dim, device):
-                    host[at:at + len(blk)] = blk.cpu().numpy(); at += len(blk)
-                full = n1 == args.rows
-                sh3 = build_shard(torch, args, n1, 0, 1, device)
-                ids_for_recall = sh3.local.search(qh, args.k)[0]
-                sh3.close()
-            else:
-                full, ids_for_recall = True, gpu_ids
-            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, host, qh, ids_for_recall, full)
-        del host
         # BASELINE configs 4 / 5, SURVEY 8 f1 / f4, and the encode leg of the metric with its breakdown (tools/bench_extras.py)
         from tools import bench_extras as bx
         rows = (("config4_probe_loop", lambda: bx.config4_probe_loop(torch, device, dim=args.dim, dtype=args.dtype, rows0=min(2_000_000, max(args.rows, 200_000)), k=args.k)),
@@ -848,6 +833,23 @@ def main():
             except Exception as e:  # the headline line must still print
                 extra[name] = {"error": repr(e)[:400]}
             torch.cuda.empty_cache()
+        # the CPU legs come LAST: their 64-128 BLAS / OpenMP threads leave the host busy for a while, and the encode rows above are
+        # host-sensitive (tokenizer threads feeding the forward: end to end 0.90-0.91 of forward-only behind the CPU legs, 0.93-0.97 in front)
+        if not args.no_cpu_baseline:
+            if host is None:                    # not enough host RAM for the full fp32 copy: first 1 M rows, scaled
+                n1 = min(args.rows, 1_000_000)
+                host = np.empty((n1, args.dim), dtype=np.float32)
+                at = 0
+                for blk in gen_rows_dev(torch, 0, n1, args.dim, device):
+                    host[at:at + len(blk)] = blk.cpu().numpy(); at += len(blk)
+                full = n1 == args.rows
+                sh3 = build_shard(torch, args, n1, 0, 1, device)
+                ids_for_recall = sh3.local.search(qh, args.k)[0]
+                sh3.close()
+            else:
+                full, ids_for_recall = True, gpu_ids
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, host, qh, ids_for_recall, full)
+        del host
     if extra:
         out["extra"] = extra
         # the secondary numbers that matter, flat, where the driver's parser keeps them (it drops `extra`)
