@@ -21,8 +21,11 @@ in a child process after the one-rank-per-GPU measurement and reports it as `sin
 After the timed loop the LAST pipelined batch is compared with a synchronous search of the same batch (must be
 bit-identical), and recall@k against the fp32 CPU ranking is computed from THOSE ids.
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HIP-event time of the scan kernel on
-its own stream, algorithmic bytes) and `cpu_baseline` (the oracle's restatement of the reference's CPU code on this
-box's host cores, bounded samples).
+its own stream, algorithmic bytes, shader clock / power sampled during the timed regions) and `cpu_baseline` (the oracle's
+restatement of the reference's CPU code on this box's host cores, bounded samples).  That final line is <= 4 KB
+(tools/bench_line.py: contract keys, `config` with the flat `x_*` secondary numbers, `roofline`, reduced `cpu_baseline`,
+`verified`); the full tree (`extra`, PMC passes, per-rank rows, prose notes) goes to an earlier stdout line that starts with
+`EXTRA ` and to `bench_extra.json` beside this script.
 """
 from __future__ import annotations
 
@@ -38,6 +41,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+from tools.bench_line import ClockSampler, emit, parse_emitted  # noqa: E402  (no torch / numpy inside)
+
+SIDE_FILE = os.path.join(ROOT, "bench_extra.json")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HIP events bracket every PROFILE_EVERY-th main scan of the timed region: the two event packets cost ~25 us on the scan stream
@@ -171,7 +178,16 @@ def make_queries(torch, n_batches, batch, dim, device, seed):
     return out
 
 
-def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFILE_EVERY, ctl="cuda", repeats=1):
+def _pci_address(torch, device):
+    """sysfs PCI address of a torch device ("0000:75:00.0") or None."""
+    try:
+        p = torch.cuda.get_device_properties(device)
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    except Exception:       # noqa: BLE001
+        return None
+
+
+def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFILE_EVERY, ctl="cuda", repeats=1, sampler=None):
     """qs: list of query batches, step i takes qs[i % len(qs)].  The timed region (exactly `steps` steps between barrier +
     synchronize on both sides, max over ranks) is run `repeats` times back to back after ONE warm-up.
     Returns (median seconds, profile, last batch's buffers, index of the query batch of the last step, all regions' seconds)."""
@@ -182,6 +198,8 @@ def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFIL
     sh.local.profile(every)       # HIP events around every `every`-th main scan of the timed regions
     dts = []
     last = None
+    if sampler is not None:        # shader clock / power while the timed regions run (a helper thread reading two sysfs files every 10 ms)
+        sampler.start()
     for _ in range(max(1, repeats)):
         if world > 1:
             dist.barrier()
@@ -199,6 +217,8 @@ def run_steps(torch, dist, sh, qs, k, steps, warmup, world, device, every=PROFIL
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         dts.append(dt)
+    if sampler is not None:
+        sampler.stop()
     sh.local.profile(False)
     prof = sh.local.profile_collect()
     ex = sh.exchange_times_ms() if sh.timing else []
@@ -270,9 +290,11 @@ def cpu_baseline(args, seconds, X, Q, gpu_ids, full_size):
                        "batched top-k comparator is `batched_value` below",
            "kind_note": "oracle/retrieval_np.py, the line-by-line numpy restatement of the reference functions (pinned to reference "
                         "outputs in tests/); the reference tree itself does not exist on the GPU box",
-           "sample": f"{done} single-query dense_passage_retrieval calls (np.dot + min-max + full argsort, fp32) over "
-                     f"{'ALL' if full_size else 'the first'} {n} rows of the bench corpus in {dt:.1f}s = {qps_sample:.3f} q/s"
-                     + ("" if full_size else f"; linearly scaled x{scale:g} to {args.rows} rows (host RAM too small for the fp32 copy)"),
+           "sample": f"{done} single-query dense_passage_retrieval calls, {'ALL' if full_size else 'first'} {n} fp32 rows, {dt:.1f}s"
+                     + ("" if full_size else f", scaled x{scale:g}"),
+           "sample_full": f"{done} single-query dense_passage_retrieval calls (np.dot + min-max + full argsort, fp32) over "
+                          f"{'ALL' if full_size else 'the first'} {n} rows of the bench corpus in {dt:.1f}s = {qps_sample:.3f} q/s"
+                          + ("" if full_size else f"; linearly scaled x{scale:g} to {args.rows} rows (host RAM too small for the fp32 copy)"),
            "host_cpus": os.cpu_count(), "threads": ti,
            "recall_at_k_vs_cpu_fp32": recall,
            "recall_note": f"top-{args.k} ids of the {args.dtype} HIP index from the LAST TIMED PIPELINED batch of the headline configuration "
@@ -468,7 +490,7 @@ def single_process_main(args):
 
     head, qs, last = run(args.batch, args.steps, args.warmup, 4321)
     out = {"metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic; corpus rows drawn by " + _generator_note(),
+           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "data_note": "corpus rows drawn by " + _generator_note(),
            "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} (north_star target config; corpus fixed, "
                                   f"row-sharded over {n} device(s) driven from ONE process)",
                       "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "process_model": f"one process, {n} shard(s) on devices {devices} (MultiDeviceIndex)",
@@ -488,7 +510,7 @@ def single_process_main(args):
         out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] = c3["last_pipelined_batch_equals_synchronous_search"]
         ok = ok and c3["last_pipelined_batch_equals_synchronous_search"]
     mi.close()
-    print(json.dumps(out), flush=True)
+    emit(out, side_path=None)
     if not ok:
         raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
 
@@ -524,14 +546,15 @@ def single_process_leg(args):
             p.kill()                                   # this exact child
             p.communicate()
             return {"error": f"timeout after {args.single_process_timeout:.0f} s"}
-        lines = [l for l in so.splitlines() if l.startswith("{")]
-        if p.returncode != 0 or not lines:
+        if p.returncode != 0:
             return {"error": f"exit code {p.returncode}", "stderr_tail": se[-600:]}
-        d = json.loads(lines[-1])
-        keep = {k_: d.get(k_) for k_ in ("value", "ms_per_step", "verified", "headline_detail", "n_gpus")}
-        keep["process_model"] = d["config"]["process_model"]
-        keep["exchange"] = d["config"]["exchange"]
-        keep["config3_batch256"] = (d.get("extra") or {}).get("config3_batch256")
+        d, side = parse_emitted(so)
+        keep = {k_: d.get(k_) for k_ in ("value", "ms_per_step", "verified", "n_gpus")}
+        keep["headline_detail"] = side.get("headline_detail")
+        cf = side.get("config_full") or {}
+        keep["process_model"] = cf.get("process_model", d["config"]["process_model"])
+        keep["exchange"] = cf.get("exchange", d["config"]["exchange"])
+        keep["config3_batch256"] = (side.get("extra") or {}).get("config3_batch256")
         keep["wall_seconds"] = time.perf_counter() - t0
         return keep
     except Exception as e:      # the headline line must still print
@@ -630,7 +653,9 @@ def main():
     sh = build_shard(torch, args, args.rows, rank, world, device, host=host, timing=world > 1)
     # >= 20 timed scan launches for `roofline`: every 4th launch by default, more often when steps x repeats is small
     every = max(1, min(PROFILE_EVERY, (args.steps * max(1, args.repeats)) // 20))
-    dt, prof, last, qi, dts = run_steps(torch, dist, sh, qs, args.k, args.steps, args.warmup, world, device, every=every, ctl=ctl, repeats=args.repeats)
+    sampler = ClockSampler(_pci_address(torch, device))
+    dt, prof, last, qi, dts = run_steps(torch, dist, sh, qs, args.k, args.steps, args.warmup, world, device, every=every, ctl=ctl, repeats=args.repeats, sampler=sampler)
+    clock = sampler.summary()
     gpu_ids, gpu_sc, same = verify_last_batch(sh, last, qs[qi].cpu().numpy(), args.k)
     if qi != 0:                 # recall is computed for batch 0 (the CPU ranking of one batch is the expensive part)
         gpu_ids = sh.search(qh, args.k)[0]
@@ -639,16 +664,18 @@ def main():
     out = {
         "metric": "top-k queries/sec", "value": head["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic; corpus rows drawn by " + generator,
-        "repeats": len(dts), "value_min": head.get("value_min", head["value"]), "value_max": head.get("value_max", head["value"]),
-        "ms_per_step_min": head.get("ms_per_step_min", head["ms_per_step"]), "ms_per_step_max": head.get("ms_per_step_max", head["ms_per_step"]),
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "data_note": "corpus rows drawn by " + generator,
+        # the final line keeps `config` / `roofline` / `cpu_baseline` / `verified`; the keys below the contract's travel on the EXTRA line
         "ms_per_step_all": head.get("ms_per_step_all", [head["ms_per_step"]]),
+        "ms_per_step_min": head.get("ms_per_step_min", head["ms_per_step"]), "ms_per_step_max": head.get("ms_per_step_max", head["ms_per_step"]),
         "timing_note": f"the timed region (exactly {args.steps} steps between barrier + synchronize, max over ranks) ran {len(dts)} times back to back after one "
                        "warm-up; value / ms_per_step are the MEDIAN region, min / max over the regions beside them",
-        "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch} "
-                               f"(north_star target config; corpus fixed, row-sharded over {world} GPU(s))",
+        "config": {"workload": f"brute-force top-{args.k} over {args.rows} x {args.dim} {args.dtype} rows, batch {args.batch}, row-sharded over {world} GPU(s) "
+                               "(north_star target config)",
                    "rows": args.rows, "dim": args.dim, "batch": args.batch, "k": args.k, "query_batches_rotated": len(qs),
                    "sharding": f"rows/{world}", "device": info["name"], "n_cu": info["n_cu"],
+                   "repeats": len(dts), "value_min": head.get("value_min", head["value"]), "value_max": head.get("value_max", head["value"]),
+                   "generator": "numpy default_rng([1234, blk]), SURVEY 8(d) literally" if SURVEY_RNG else "torch device randn per 250K-row block, rows L2-normalised (SURVEY 8(d) distribution)",
                    "exchange": "none (1 shard)" if world == 1 else f"one packed-u64 all-gather per batch ({ex64} binding over {args.backend}"
                                                                    f"{', ranks share cuda:0, keys staged through the host' if args.share_device else ''}) + device key merge"},
         "roofline": {"bound": "hbm", "achieved": head["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac_of_8TBps"],
@@ -656,7 +683,7 @@ def main():
                      "kernel": "scan_kernel (fused MFMA scan + top-k)", "kernel_ms": head["kernel_ms"], "two_scan_streams": head["two_scan_streams"],
                      "achieved_is": "algorithmic bytes / step time (launches overlap: no per-launch duration)" if head["two_scan_streams"] else "algorithmic bytes / HIP-event time of the scan on its stream",
                      "algorithmic_bytes_per_launch": prof["bytes_per_launch"], "launches_timed": prof["launches"], "timed_every": every,
-                     "rows_per_gpu": len(sh)},
+                     "rows_per_gpu": len(sh), "clock": clock},
         "verified": {"last_pipelined_batch_equals_synchronous_search": same},
     }
     if not same:
@@ -678,10 +705,12 @@ def main():
             q256 = make_queries(torch, max(1, min(args.query_batches, 3)), 256, args.dim, device, 8765)
             steps_w = max(10, args.steps // 2)
             shw = sh.view(ex256, timing=world > 1) if world > 1 else sh
-            dtw, profw, lastw, qiw, dtsw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl, repeats=min(3, max(1, args.repeats)))
+            samp_w = ClockSampler(_pci_address(torch, device))
+            dtw, profw, lastw, qiw, dtsw = run_steps(torch, dist, shw, q256, args.k, steps_w, 3, world, device, ctl=ctl, repeats=min(3, max(1, args.repeats)), sampler=samp_w)
             _, _, same_w = verify_last_batch(shw, lastw, q256[qiw].cpu().numpy(), args.k)
             c3 = summarise(256, steps_w, dtw, profw, len(sh), args.dim, dual=bool(sh.local.get_option("pipe_dual_scan_wide_active")), dts=dtsw)
             c3["kernel"] = "scan_wide_kernel (256 queries resident in registers, LDS-DMA corpus ring)"
+            c3["clock"] = samp_w.summary()
             c3["frac_of_2500TF_bf16"] = c3["mfma_TFLOPs"] / MFMA_BF16_PEAK_TFLOPS
             c3["last_pipelined_batch_equals_synchronous_search"] = same_w
             c3["exchange_binding"] = ex256 if world > 1 else None
@@ -721,7 +750,7 @@ def main():
             out["extra"] = {"config3_batch256": {"error": why}}
             out["multi_rank_extras"] = "abandoned: " + why
             if rank == 0:
-                print(json.dumps(out), flush=True)
+                emit(out, side_path=SIDE_FILE)
             os._exit(0)                 # ranks may sit in a dead collective: no further collectives, no clean teardown
     else:
         _after_headline()
@@ -745,7 +774,7 @@ def main():
         if "error" not in tr:
             out["roofline"]["traffic"] = tr["traffic_bytes_per_launch"]
             out["roofline"]["traffic_over_algorithmic"] = tr["traffic_bytes_per_launch"] / prof["bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py itself (4 steps), FETCH x 2 (gfx950)"
+            out["roofline"]["traffic_source"] = "pmc passes of this run (rocprofv3), FETCH x 2 + WRITE"
             out["roofline"]["traffic_launches"] = tr["raw"]["FETCH_SIZE"]["launches"]
             out["roofline"]["traffic_kernel_us_under_pmc"] = tr["raw"]["FETCH_SIZE"]["avg_kernel_us"]
             out["pmc_this_run"] = tr
@@ -759,8 +788,7 @@ def main():
                 w = pj.get("workload", {})
                 if (w.get("rows"), w.get("dim"), w.get("dtype"), w.get("batch"), w.get("k")) == (rows_here, args.dim, args.dtype, args.batch, args.k):
                     out["roofline"]["traffic"] = pj["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = (f"FALLBACK profiles/{os.path.basename(prof_file)}: a committed measurement of this command from an earlier "
-                                                         "round, NOT of this run")
+                    out["roofline"]["traffic_source"] = f"FALLBACK profiles/{os.path.basename(prof_file)} (earlier round, NOT this run)"
                     break
     out["cpu_baseline"] = None
     extra = {}
@@ -858,6 +886,8 @@ def main():
                 d_ = d_.get(p_) if isinstance(d_, dict) else None
             return d_
         flat = {"config3_batch256_kernel_ms": _get(extra, "config3_batch256", "kernel_ms"), "config3_batch256_qps": _get(extra, "config3_batch256", "value"),
+                "config3_sclk_mhz": _get(extra, "config3_batch256", "clock", "sclk_mhz_median"), "config3_power_w": _get(extra, "config3_batch256", "clock", "power_w_mean"),
+                "config3_frac_of_2500TF": _get(extra, "config3_batch256", "frac_of_2500TF_bf16"),
                 "config2_1M_rows_ms_per_step": _get(extra, f"config2_{min(args.rows, 1_000_000)}_rows_batch{args.batch}", "ms_per_step"),
                 "config2_1M_rows_qps": _get(extra, f"config2_{min(args.rows, 1_000_000)}_rows_batch{args.batch}", "value"),
                 "shard_1p25M_rows_batch256_ms_per_step": _get(extra, f"config3_one_of_8_shards_{min(args.rows, 1_250_000)}_rows_batch256", "ms_per_step"),
@@ -868,7 +898,14 @@ def main():
                 "config5_end_to_end_over_forward_only": _get(extra, "config5_bge_large_fp16_encode_search_rescore", "encode", "end_to_end_over_forward_only"),
                 "single_query_latency_1M_rows_us": _get(extra, "single_query_latency", "rows", str(min(args.rows, 1_000_000))),
                 "config4_search_us_per_call": _get(extra, "config4_probe_loop", "search_us_per_call"),
-                "config4_call_frac_of_hbm": _get(extra, "config4_probe_loop", "frac")}
+                "config4_call_frac_of_hbm": _get(extra, "config4_probe_loop", "frac"),
+                "f1_selfjoin_bf16_s": _get(extra, "f1_synonymy_selfjoin", "bf16", "threshold_search_whole_join_s"),
+                "f1_selfjoin_bf16_frac_of_2500TF": _get(extra, "f1_synonymy_selfjoin", "bf16", "frac"),
+                "f4_ppr_comorag_scale_us": _get(extra, "f4_dpr_seeded_ppr", "comorag_scale", "fused_us_per_query"),
+                "f4_ppr_1M_passages_us": _get(extra, "f4_dpr_seeded_ppr", "at_1M_passages", "fused_us_per_query"),
+                "attention_us_per_layer_bf16": _get(extra, "corpus_embed_bf16", "attention_us_per_layer"),
+                "encoder_gelu_path": _get(extra, "corpus_embed_bf16", "gelu_path"),
+                "encoder_parity_min_row_cosine": _get(extra, "corpus_embed_bf16", "parity_vs_fp32_oracle", "min_row_cosine_vs_fp32_oracle")}
         out["config"].update({f"x_{k_}": v_ for k_, v_ in flat.items() if v_ is not None})
     left_cleanly = True
     if world > 1:
@@ -889,7 +926,7 @@ def main():
         elif rank == 0 and not left_cleanly:
             out["single_process"] = {"error": "skipped: the ranks did not leave the process group within 120 s"}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, side_path=SIDE_FILE)
     if not left_cleanly:
         os._exit(0 if (same and same_w) else 1)
     if not (same and same_w):

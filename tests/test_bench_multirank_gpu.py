@@ -11,8 +11,21 @@ import sys
 
 import pytest
 
+from tools.bench_line import LINE_LIMIT, parse_emitted
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line_and_side(stdout):
+    """The final line (the ONLY stdout line that starts with `{`, <= 4 KB, contract keys) and the EXTRA record printed before it."""
+    line, side = parse_emitted(stdout)
+    last = [l for l in stdout.splitlines() if l.strip()][-1]
+    assert last.startswith("{") and len(last) <= LINE_LIMIT and json.loads(last) == line
+    assert set(line) == {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                         "data", "config", "roofline", "cpu_baseline", "verified"}
+    assert line["data"] == "synthetic"
+    return line, side
 
 
 @pytest.mark.timeout(900)
@@ -23,23 +36,21 @@ def test_bench_two_ranks_sharing_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-device", "--rows", "300000",
                         "--steps", "8", "--warmup", "2"], capture_output=True, text=True, timeout=850, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                        # ONE line, from rank 0
-    out = json.loads(lines[0])
+    out, side = _line_and_side(r.stdout)                            # ONE line, from rank 0
     assert out["n_gpus"] == 2 and out["steps"] == 8 and out["value"] > 0
     assert out["verified"]["last_pipelined_batch_equals_synchronous_search"] is True
     assert out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] is True
-    assert out["exchange_bindings"]["backend"] == "gloo" and out["exchange_bindings"]["torch_world_size"] == 2
-    assert [p["rank"] for p in out["per_rank"]] == [0, 1] and sum(p["rows"] for p in out["per_rank"]) == 300000
+    assert side["exchange_bindings"]["backend"] == "gloo" and side["exchange_bindings"]["torch_world_size"] == 2
+    assert [p["rank"] for p in side["per_rank"]] == [0, 1] and sum(p["rows"] for p in side["per_rank"]) == 300000
     # 150 K-row shards are short scans: the passes alternate between two scan streams (no per-launch duration, a lifetime
     # instead)
-    assert all((p[b]["kernel_ms"] or p[b]["kernel_lifetime_ms"]) > 0 for p in out["per_rank"] for b in ("batch64", "batch256"))
+    assert all((p[b]["kernel_ms"] or p[b]["kernel_lifetime_ms"]) > 0 for p in side["per_rank"] for b in ("batch64", "batch256"))
     assert out["roofline"]["two_scan_streams"] is True and out["roofline"]["kernel_ms"] is None
-    assert out["extra"]["config3_batch256"]["last_pipelined_batch_equals_synchronous_search"] is True
-    assert out["roofline"]["rows_per_gpu"] == 150000
+    assert side["extra"]["config3_batch256"]["last_pipelined_batch_equals_synchronous_search"] is True
+    assert out["roofline"]["rows_per_gpu"] == 150000 and out["config"]["x_config3_batch256_qps"] > 0 and out["config"]["x_single_process_qps"] > 0
     # rank 0 then ran the SAME workload through the single-process index (MultiDeviceIndex, what hooks.install builds for
     # num_shards = 2) in a child process: two logical shards on cuda:0 here
-    sp = out["single_process"]
+    sp = side["single_process"]
     assert "error" not in sp, sp
     assert sp["value"] > 0 and sp["verified"]["last_pipelined_batch_equals_synchronous_search"] is True
     assert sp["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] is True
@@ -56,10 +67,8 @@ def test_bench_single_process_mode_four_logical_shards():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process", "--gpus", "4", "--share-device", "--rows", "600000",
                         "--steps", "12", "--warmup", "2"], capture_output=True, text=True, timeout=550, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 4 and out["steps"] == 12 and out["value"] > 0 and out["single_process"] is True
+    out, side = _line_and_side(r.stdout)
+    assert out["n_gpus"] == 4 and out["steps"] == 12 and out["value"] > 0 and side["single_process"] is True
     assert out["config"]["shard_rows"] == [150000] * 4
     assert out["verified"] == {"last_pipelined_batch_equals_synchronous_search": True, "batch256_last_pipelined_batch_equals_synchronous_search": True}
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
@@ -82,18 +91,16 @@ def test_bench_eight_ranks_sharing_one_gpu():
         first = [l for l in r.stderr.splitlines() if "Gloo" not in l][-15:]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=700, env=env)
         assert r.returncode == 0, ("first attempt:", first, "second attempt:", [l for l in r.stderr.splitlines() if "Gloo" not in l][-25:])
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 8 and out["steps"] == 4 and out["repeats"] == 2 and out["value"] > 0
-    assert out["value_min"] <= out["value"] <= out["value_max"] and len(out["ms_per_step_all"]) == 2
+    out, side = _line_and_side(r.stdout)
+    assert out["n_gpus"] == 8 and out["steps"] == 4 and out["config"]["repeats"] == 2 and out["value"] > 0
+    assert out["config"]["value_min"] <= out["value"] <= out["config"]["value_max"] and len(side["ms_per_step_all"]) == 2
     assert all(v is True for v in out["verified"].values()) and len(out["verified"]) == 2, out["verified"]
-    eb = out["exchange_bindings"]
+    eb = side["exchange_bindings"]
     assert eb["backend"] == "gloo" and eb["torch_world_size"] == 8 and eb["share_device"] is True and eb["batch64"] == "torch" and eb["batch256"] == "torch"
-    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and [p["rows"] for p in out["per_rank"]] == [10000] * 8
-    assert all(p["batch64"] and p["batch256"] for p in out["per_rank"])
+    assert [p["rank"] for p in side["per_rank"]] == list(range(8)) and [p["rows"] for p in side["per_rank"]] == [10000] * 8
+    assert all(p["batch64"] and p["batch256"] for p in side["per_rank"])
     assert out["roofline"]["rows_per_gpu"] == 10000 and out["config"]["sharding"] == "rows/8"
-    sp = out["single_process"]
+    sp = side["single_process"]
     assert "error" not in sp, sp
     assert sp["n_gpus"] == 8 and sp["value"] > 0 and "one process, 8 shard(s)" in sp["process_model"]
     assert all(v is True for v in sp["verified"].values()) and len(sp["verified"]) == 2
