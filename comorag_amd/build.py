@@ -28,8 +28,7 @@ LIB = os.path.join(LIBDIR, "libcomorag_hip.so")
 STAMP = os.path.join(LIBDIR, "build_stamp.json")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# (-Wno-inline-asm: the wide kernel's LDS-DMA statements list m0 as a clobber on purpose — cdna_hip_programming.md §5.7 — and hipcc warns once per inlined copy)
-FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"] + os.environ.get("CMR_EXTRA_HIPCC_FLAGS", "").split()
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + os.environ.get("CMR_EXTRA_HIPCC_FLAGS", "").split()
 if os.environ.get("CMR_BUILD_LIB"):          # experiment builds go to their own file (load with COMORAG_HIP_LIB=...)
     LIB = os.environ["CMR_BUILD_LIB"]
     STAMP = LIB + ".stamp.json"

@@ -636,6 +636,8 @@ static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int
     }
     constexpr size_t kDynLds = 160 * 1024 - 17 * 1024;                          // the kernel's static LDS (selection stage, carry and final rows) takes 16.3 KiB
     if (!g.kind || lds > kDynLds) return hipErrorInvalidValue;
+    // the kernel's selections: kind 1 streams <= 1024 rows, kind 2 up to workgroups x k candidates (> 1024 possible) — cmr_select.h's rule
+    if (!out_full && !tiny_select_stream_ok(g.kind == 1 ? (long long)npanels * CMR_PANEL_ROWS : (long long)g.nwg * k + 1025, k)) return hipErrorInvalidValue;
     const int stage_raw = lds + (size_t)nq * dim * 4 <= kDynLds ? 1 : 0;          // fp32 at 1024-d: the operands alone take 128 KiB
     if (stage_raw) lds += (size_t)nq * dim * 4;
     const v4u* c = reinterpret_cast<const v4u*>(corpus);

@@ -87,12 +87,18 @@ __device__ __forceinline__ void tiny_select(u64 (&key)[16], int k, u64* stage, i
 // The same selection over a STREAM of n keys (fetch(i), 0 beyond n): one chunk of <= 1024 keys, or — k <= 64 — chunks of
 // 960 with the running k best carried along in the wave's LDS row (slot 15 of lanes 0 .. k-1).
 // PRECONDITION: n <= 1024 or k <= 64.  The single-chunk branch looks at the first 1024 keys only, and the carry row holds 64
-// keys: a stream longer than 1024 with k > 64 has no correct route here.  The callers keep clear of it (cmr_launch_scan_fin
-// rejects k > 64, the tiny path stops at 1024 rows for larger k); a call that breaks the rule traps instead of dropping keys.
+// keys: a stream longer than 1024 with k > 64 has no correct route here (tiny_select_stream_ok below).
+// The host-side launch wrappers (tiny_launch, cmr_launch_scan_fin) refuse a launch this predicate rejects — the SAME function, so the
+// guard and the invariant cannot drift apart; the device-side trap is left to development builds (a trap aborts the whole HIP context
+// and every index of the process with it).
+__host__ __device__ constexpr bool tiny_select_stream_ok(long long n, int k) { return n <= 1024 || k <= 64; }
+
 template <class Fetch, class Emit>
 __device__ __forceinline__ void tiny_select_stream(int n, int k, u64* stage, u64* carry, int lane, Fetch fetch, Emit emit) {
     u64 key[16];
-    if (__builtin_expect(n > 1024 && k > 64, 0)) __builtin_trap();
+#ifdef CMR_DEV_KNOBS
+    if (__builtin_expect(!tiny_select_stream_ok(n, k), 0)) __builtin_trap();
+#endif
     if (n <= 1024) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) key[j] = fetch(lane + 64 * j);

@@ -29,6 +29,10 @@
 #include "cmr_kernels.h"
 #include "cmr_select.h"
 
+// this translation unit only: the wide kernel's LDS-DMA statements list m0 as a clobber on purpose (cdna_hip_programming.md 5.7) and hipcc
+// warns once per inlined copy; asm diagnostics stay on in every other file
+#pragma clang diagnostic ignored "-Winline-asm"
+
 #define MODE_TOPK 0
 #define MODE_SCORES 1
 // MODE_FIN: top-k with the thresholds AND the final selection inside the launch (a synchronous caller's handful of queries on a
@@ -1162,7 +1166,7 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
     constexpr int STG = NW == 8 ? WIDE8_STG : WIDE_STG;         // staging records per wave (LDS budget)
     static_assert(NW == 4 || (NW == 8 && NT == 1), "8 waves hold one tile each");
     static_assert(NW == 4 || (size_t)STG * 16 <= (size_t)(CAP + 2) * 8, "8-wave kernel: the staging records live in the compaction stage");
-    static_assert(KS % GRP == 0 && GRP % NW == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && NST >= 3, "group geometry");
+    static_assert(KS % GRP == 0 && GRP % NW == 0 && GRP % ADEPTH == 0 && ADEPTH % 4 == 0 && NST >= 4, "group geometry (a 3-stage ring was measured with a -DWIDE4_NST3=3 build in round 5 and not kept: no shipped or tested configuration has fewer than 4 stages)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1174,6 +1178,9 @@ __global__ __launch_bounds__(NW * 64, 1) void scan_wide_kernel(ScanP P) {
     static_assert(PPG * QPP == GRP / 4, "DMA pieces spread evenly over the quads of a group");
     constexpr int KREG = KS - KLDS;               // k-steps of a tile resident in registers; the last KLDS sit in LDS
     constexpr bool ACCV = NT == 2 && NW == 4 && CMR_WIDE_ACC_VGPR;     // accumulators in the VGPR half (see CMR_WIDE_ACC_VGPR)
+    // the LDS-tail branch of the MFMA chain (ks >= KREG) issues mma_asm with an AGPR accumulator: with ACCV the compiler would wrap every
+    // such MFMA in accvgpr copies around opaque asm (no wait states padded).  No NT = 2 / NW = 4 configuration has an LDS tail today.
+    static_assert(!ACCV || KLDS == 0, "accumulators in VGPRs need every k-step's B-operand in registers (KLDS = 0)");
     constexpr int AMOVE = ACCV ? 16 : WIDE_AMOVE;                       // NT = 2: k-steps of tile 0 whose B-operand lives in the AGPR half
 // an empty / nop statement that makes an accumulator opaque at this point, whichever register file holds it
 #define CMR_ACC_ASM(TEXT, C) do { if constexpr (ACCV) asm volatile(TEXT : "+v"(C)); else asm volatile(TEXT : "+a"(C)); } while (0)
@@ -1648,7 +1655,7 @@ hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipS
 // top-k scan with thresholds and final selection inside the launch (MODE_FIN: one query tile, <= fin_ns <= 1024 first-panel slots)
 hipError_t cmr_launch_scan_fin(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
     if (g.nqt != 1 || a.qgroups > 1 || !a.fin || !a.fin_pmax || !a.fin_tau || !a.fin_dense || a.fin_wgs < 1 || a.fin_wgs * CMR_SCAN_WAVES > CMR_FIN_SLOTS ||
-        a.fin_wgs > g.grid || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || a.k > 64 || a.nq > CMR_FIN_MAX_QUERIES || !a.out_ids || !a.out_scores || a.sample_waves > 0)
+        a.fin_wgs > g.grid || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || !tiny_select_stream_ok((long long)a.fin_dcap + 1025, a.k) || a.nq > CMR_FIN_MAX_QUERIES || !a.out_ids || !a.out_scores || a.sample_waves > 0)
         return hipErrorInvalidValue;
     const ScanP p = to_p(g, a);
     CmrScanGeom gf = g;

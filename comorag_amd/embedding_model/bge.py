@@ -119,7 +119,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                 reason = "left-padding tokenizer"
             if reason is None:
                 self._fused = fused_bert.FusedBertLayers(self.embedding_model, graphs=int(cfg_get(self.global_config, "embedding_hip_graphs", 24)),
-                                                         gelu=str(cfg_get(self.global_config, "embedding_gelu", "epilogue")))
+                                                         gelu=str(cfg_get(self.global_config, "embedding_gelu", "exact")))
                 self.encoder_path = "hip-fused-layers"
             else:
                 self.encoder_path = f"transformers ({reason})"
@@ -144,7 +144,7 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         # texts), in the background — that call goes on with threads until the workers answer; N > 0: N processes from the start.
         # (Same-box probe of every mode at BERT-base bf16, tools/tok_mode_probe.py: end to end 0.78-0.92 of forward-only for ALL of them,
         # run-to-run spread larger than any difference between them — the lever was the tokenizer call itself, see _ragged.)
-        self._tok_procs, self._tok_procs_starting = None, None
+        self._tok_procs, self._tok_procs_starting, self._closed = None, None, False
         n_procs = int(cfg_get(self.global_config, "embedding_tokenizer_processes", 0))
         self._tok_procs_auto = (min(4 if n_procs == -1 else -n_procs, max(1, (os.cpu_count() or 2) // 4)) if n_procs < 0 else 0) if self._fast_tok else 0
         if n_procs > 0 and self._fast_tok:
@@ -164,7 +164,12 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         tok = self.tokenizer
         pool = mp.get_context("spawn").Pool(min(int(n), os.cpu_count() or 1), initializer=_tokworker.init,
                                             initargs=(tok.backend_tokenizer.to_str(), getattr(tok, "truncation_side", "right"), "longest_first"))
-        pool.apply(_tokworker.ragged, (["warm up"], 16))        # the workers have imported `tokenizers` and rebuilt the tokenizer
+        try:        # the workers have imported `tokenizers` and rebuilt the tokenizer — or the pool goes (workers that die in their
+                    # initializer are respawned by mp.Pool for ever: a blocking apply() would never return)
+            pool.apply_async(_tokworker.ragged, (["warm up"], 16)).get(timeout=120.0)
+        except BaseException:
+            pool.terminate()
+            raise
         return pool
 
     def _maybe_start_tok_procs(self, n_texts: int, window_texts: int) -> None:
@@ -176,9 +181,15 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
 
         def _go():
             try:
-                self._tok_procs = self._start_tok_procs(self._tok_procs_auto)
+                pool = self._start_tok_procs(self._tok_procs_auto)
             except Exception:                     # no worker processes on this host: the threads stay
                 self._tok_procs_auto = 0
+                return
+            with self._bt_lock:                   # close() may have given up waiting for this thread: a pool published now would never be terminated
+                if self._closed:
+                    pool.terminate()
+                else:
+                    self._tok_procs = pool
         with self._bt_lock:                  # ComoRAG encodes from up to 16 threads over one model instance: ONE of them starts the workers
             if self._tok_procs_starting is not None:
                 return
@@ -421,9 +432,13 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         if starting is not None and starting.is_alive():
             starting.join(30.0)                   # a pool still being spawned: let it finish, then take it down with the rest
         self._tok_procs_auto = 0
-        if getattr(self, "_tok_procs", None) is not None:
-            self._tok_procs.terminate()
-            self._tok_procs = None
+        lock = getattr(self, "_bt_lock", None)
+        if lock is not None:
+            with lock:                            # a starter thread that outlives the join sees the flag and terminates its own pool
+                self._closed = True
+                pool, self._tok_procs = getattr(self, "_tok_procs", None), None
+            if pool is not None:
+                pool.terminate()
         if getattr(self, "_tok_pool", None) is not None:
             self._tok_pool.shutdown(wait=False)
 

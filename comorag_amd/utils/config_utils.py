@@ -40,7 +40,7 @@ class BaseConfig:
     embedding_forward_batches: int = 1            # length-bucketed path: a forward mini-batch holds up to this many reference batches' worth of tokens
     embedding_hip_graphs: int = 24                # fused encoder: mini-batch shapes kept as captured hipGraphs (0 = launch every forward eagerly)
     embedding_fused_encoder: bool = True          # 16-bit BERT encoders: HIP attention + bias/residual/LayerNorm stages, one QKV GEMM (embedding_model/fused_bert.py)
-    embedding_gelu: str = "epilogue"              # fused encoder: "epilogue" = FFN-up bias + GELU (tanh form) inside the hipBLASLt GEMM; "exact" = separate erf-form GELU kernel
+    embedding_gelu: str = "exact"                 # fused encoder: "exact" = erf-form GELU kernel (the reference's function); "epilogue" = opt-in: FFN-up bias + GELU inside the hipBLASLt GEMM (TANH form, <= 4.8e-4 per activation away, ~7 % faster forward)
 
 
 def cfg_get(cfg, name, default):

@@ -166,8 +166,8 @@ def test_fused_layer_stack_vs_transformers_forward_and_oracle(dtype):
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
 def test_gelu_in_the_gemm_epilogue_vs_the_exact_kernel_vs_oracle(dtype):
-    """`embedding_gelu = "epilogue"` (default): FFN-up GEMM + bias + GELU as ONE hipBLASLt launch, GELU in its tanh form;
-    `"exact"`: the GEMM, then PyTorch's erf-form kernel (what transformers runs).  Both stacks are held to the SAME bar against the fp32
+    """`embedding_gelu = "epilogue"` (opt-in): FFN-up GEMM + bias + GELU as ONE hipBLASLt launch, GELU in its tanh form;
+    `"exact"` (default): the GEMM, then PyTorch's erf-form kernel (what transformers runs).  Both stacks are held to the SAME bar against the fp32
     oracle (erf form, BGEEmbedding.py:119), and to each other within the 16-bit rounding of the activations they differ in."""
     import torch
     from comorag_amd.embedding_model import _get_embedding_model_class
@@ -198,6 +198,61 @@ def test_gelu_in_the_gemm_epilogue_vs_the_exact_kernel_vs_oracle(dtype):
         assert float(np.min((got * want).sum(1))) > 0.999          # north_star: cosine within 1e-3 of the reference path
         assert np.abs(got @ got.T - want @ want.T).max() < 1e-3     # every pairwise score within 1e-3
     assert np.abs(out["epilogue"][0] - out["exact"][0]).max() <= tol
+
+
+@pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
+def test_both_gelu_paths_on_heavy_tailed_pre_activations_at_bert_base_depth(dtype):
+    """The exactness gate of the opt-in epilogue path.  Real BGE weights are not in the image, and seed-initialised
+    BERT pre-activations are near-Gaussian with |x| < 4 — so the FFN-up rows of a 12-layer BERT-base shape get log-normal scales
+    (a scale mixture over the units) until the pre-activations of EVERY layer are heavy-tailed (kurtosis >> 3, |x| beyond 8,
+    a good share of them in the 2 <= |x| <= 3.5 band where the tanh and erf forms of GELU differ most).  Both paths are held to
+    min row cosine >= 0.9995 and every pairwise score within 5e-4 of the fp32 oracle (erf form, BGEEmbedding.py:119-120); the default
+    must be the exact one."""
+    import torch
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.utils.config_utils import BaseConfig
+    from oracle import encode_torch as enc
+    assert BaseConfig().embedding_gelu == "exact"
+    tdt = getattr(torch, dtype)
+    model, tok = enc.tiny_bert(hidden=768, layers=12, heads=12, inter=3072, max_pos=128)
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for lyr in model.encoder.layer:
+            lyr.attention.self.query.weight.mul_(8.0)
+            lyr.attention.self.key.weight.mul_(8.0)
+            w = lyr.intermediate.dense.weight
+            # a scale mixture over the units: unit j's pre-activation is ~N(0, s_j^2), s_j log-normal (a sum over 768 inputs is Gaussian
+            # per unit whatever the weights' law: the heavy tail has to come from the units' scales) — kurtosis ~ 3 exp(4 * 0.7^2) ~ 20
+            scale = torch.exp(0.7 * torch.randn((w.shape[0], 1), generator=g))
+            w.copy_(torch.randn(w.shape, generator=g) * scale * (1.2 / 768 ** 0.5))
+            lyr.intermediate.dense.bias.copy_(torch.randn(w.shape[0], generator=g) * 0.5)
+        model.to(tdt).float()
+    texts = [f"the prince and the golden slipper number {i} " + "and the bird in the tree " * (i % 9) for i in range(15)] + ["midnight"]
+    pre = []
+    hooks = [lyr.intermediate.dense.register_forward_hook(lambda m, i, o: pre.append(o.detach().flatten())) for lyr in model.encoder.layer]
+    want = enc.batch_encode(model, tok, texts, batch_size=8, max_length=128)
+    for h in hooks:
+        h.remove()
+    for x in pre:                                                              # the regime, layer by layer (padding rows included: same weights)
+        x = x.double()
+        kurt = float(((x - x.mean()) ** 4).mean() / x.var() ** 2)
+        band = float(((x.abs() >= 2.0) & (x.abs() <= 3.5)).double().mean())
+        assert kurt > 6.0 and float(x.abs().max()) >= 8.0 and band > 0.05, (kurt, float(x.abs().max()), band)
+    cls = _get_embedding_model_class("bge-tiny-random")
+    rep = {}
+    for mode in ("exact", "epilogue"):
+        cfg = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=8, embedding_max_seq_len=128, embedding_model_dtype=dtype, embedding_gelu=mode)
+        em = cls(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+        assert em.encoder_path == "hip-fused-layers"
+        got = em.batch_encode(texts).astype(np.float64)
+        path = em._fused.gelu_path
+        em.close()
+        w64 = want.astype(np.float64)
+        rep[mode] = (path, float((got * w64).sum(1).min()), float(np.abs(got @ got.T - w64 @ w64.T).max()))
+    print("heavy-tailed GELU gate", dtype, rep)
+    assert rep["exact"][0] == "exact-erf-kernel"
+    for mode, (path, cos, pair) in rep.items():
+        assert cos >= 0.9995 and pair <= 5e-4, (mode, path, cos, pair)
 
 
 def test_fused_forward_launches_no_gelu_kernel():

@@ -148,7 +148,7 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
     em.batch_encode(chunks[:2 * batch])
     torch.cuda.synchronize(device)
     if tok_processes < 0 and em._tok_procs_auto:
-        # the default (-1) starts the tokenizer worker processes at the first corpus-sized call, in the background; the timed call below
+        # -1 (opt-in; BaseConfig's default is 0 = threads) starts the tokenizer worker processes at the first corpus-sized call, in the background; the timed call below
         # is the steady state of a corpus encode, so the start-up (about a second, once per model) happens here, untimed
         em._maybe_start_tok_procs(1 << 30, 1)
         if em._tok_procs_starting is not None:
