@@ -510,6 +510,21 @@ def single_process_main(args):
         out["verified"]["batch256_last_pipelined_batch_equals_synchronous_search"] = c3["last_pipelined_batch_equals_synchronous_search"]
         ok = ok and c3["last_pipelined_batch_equals_synchronous_search"]
     mi.close()
+    if not args.no_extra:
+        # the corpus encode over the same devices from the same ONE process: a replica of the layer stack per device (`embedding_devices`;
+        # with --share-device: logical replicas on cuda:0), bucketing windows dealt round them, rows gathered device to device
+        try:
+            from tools import bench_extras as bx
+            torch.cuda.empty_cache()
+            e1 = bx.encode_breakdown(torch, dev0, "base", "bf16", 512, parity=False)[0]
+            er = bx.encode_breakdown(torch, dev0, "base", "bf16", 512 * max(1, min(n, 4)), parity=False, devices=sorted(set(devices)), replicas=n)[0]
+            keep = ("value", "chunks", "forward_only_chunks_per_s", "tokenizer_only_chunks_per_s", "encode_replicas", "gelu_path")
+            out.setdefault("extra", {})["corpus_embed_bf16_replicas"] = {"one_replica": {k_: e1.get(k_) for k_ in keep}, "replicas": {k_: er.get(k_) for k_ in keep},
+                                                                         "speedup": er["value"] / e1["value"]}
+            out["config"]["x_corpus_embed_bf16_chunks_per_s"] = er["value"]
+            out["config"]["x_corpus_embed_bf16_one_replica_chunks_per_s"] = e1["value"]
+        except Exception as e:      # noqa: BLE001
+            out.setdefault("extra", {})["corpus_embed_bf16_replicas"] = {"error": repr(e)[:300]}
     emit(out, side_path=None)
     if not ok:
         raise SystemExit("bench: pipelined outputs differ from the synchronous search of the same batch")
@@ -555,6 +570,7 @@ def single_process_leg(args):
         keep["process_model"] = cf.get("process_model", d["config"]["process_model"])
         keep["exchange"] = cf.get("exchange", d["config"]["exchange"])
         keep["config3_batch256"] = (side.get("extra") or {}).get("config3_batch256")
+        keep["corpus_embed_bf16_replicas"] = (side.get("extra") or {}).get("corpus_embed_bf16_replicas")
         keep["wall_seconds"] = time.perf_counter() - t0
         return keep
     except Exception as e:      # the headline line must still print
@@ -731,9 +747,23 @@ def main():
                     out["exchange_bindings"]["rccl_ranks_seen"] = repr(e)[:200]
             mine = {"rank": rank, "rows": len(sh), "device": str(device), "batch64": {k_: head.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")},
                     "batch256": {k_: c3.get(k_) for k_ in ("kernel_ms", "kernel_lifetime_ms", "exchange_ms", "merge_ms", "ms_per_step")} if c3 else None}
+            if not args.no_extra:
+                # the encode half of the metric shards as the rows do (chunks are independent; the reference: device_map="auto",
+                # BGEEmbedding.py:77): every rank encodes its own chunks on its own GPU at the same time — per rank and summed
+                try:
+                    from tools import bench_extras as bx
+                    dist.barrier()
+                    e_ = bx.encode_breakdown(torch, device, "base", "bf16", 256, parity=False)[0]
+                    mine["corpus_embed_bf16"] = {k_: e_.get(k_) for k_ in ("value", "forward_only_chunks_per_s", "tokenizer_only_chunks_per_s", "chunks", "gelu_path", "encoder_path")}
+                except Exception as e:      # noqa: BLE001
+                    mine["corpus_embed_bf16"] = {"error": repr(e)[:200]}
             box = [None] * world
             dist.all_gather_object(box, mine)
             out["per_rank"] = box
+            rates = [(p_.get("corpus_embed_bf16") or {}).get("value") for p_ in box]
+            if all(isinstance(v_, float) for v_ in rates):
+                out["config"]["x_corpus_embed_bf16_chunks_per_s_sum_over_ranks"] = float(sum(rates))
+                out["config"]["x_corpus_embed_bf16_chunks_per_s_min_rank"] = float(min(rates))
 
     if world > 1:
         import threading
@@ -923,6 +953,9 @@ def main():
             out["single_process"] = single_process_leg(args)
             if isinstance(out["single_process"].get("value"), float):
                 out["config"]["x_single_process_qps"] = out["single_process"]["value"]
+            er_ = ((out["single_process"].get("corpus_embed_bf16_replicas") or {}).get("replicas") or {}).get("value")
+            if isinstance(er_, float):
+                out["config"]["x_single_process_corpus_embed_bf16_chunks_per_s"] = er_
         elif rank == 0 and not left_cleanly:
             out["single_process"] = {"error": "skipped: the ranks did not leave the process group within 120 s"}
     if rank == 0:

@@ -84,6 +84,33 @@ def pool_l2norm(hidden, mask, normalize: bool = True):
     return out
 
 
+class _EncodeReplica:
+    """One data-parallel copy of the encoder for corpus encodes: the layer stack on `device` (the owner's own model for the first
+    replica, the same weights again for logical replicas on the owner's device, a deep copy on any other GPU), a stream and a worker
+    thread of its own.  Captured mini-batch graphs belong to the replica's FusedBertLayers."""
+
+    def __init__(self, owner, device, first: bool):
+        import copy
+        import torch
+        from . import fused_bert
+        self.device = device
+        if first:
+            self.model, self.fused = owner.embedding_model, owner._fused
+        else:
+            same = device == owner.device
+            self.model = owner.embedding_model if same else copy.deepcopy(owner.embedding_model).to(device).eval()
+            with torch.cuda.device(device):
+                self.fused = fused_bert.FusedBertLayers(self.model, graphs=owner._fused.graphs, gelu="epilogue" if owner._fused.gelu_path.startswith("hipblaslt") else "exact")
+        self.stream = torch.cuda.Stream(device)
+        self.pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"cmr-enc-{device.index}")
+        self.first = first
+
+    def close(self) -> None:
+        self.pool.shutdown(wait=True)
+        if not self.first:
+            self.fused.release()
+
+
 class HipBGEEmbeddingModel(BaseEmbeddingModel):
     def __init__(self, global_config: Optional[BaseConfig] = None, embedding_model_name: Optional[str] = None,
                  model=None, tokenizer=None) -> None:
@@ -149,6 +176,23 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         self._tok_procs_auto = (min(4 if n_procs == -1 else -n_procs, max(1, (os.cpu_count() or 2) // 4)) if n_procs < 0 else 0) if self._fast_tok else 0
         if n_procs > 0 and self._fast_tok:
             self._tok_procs = self._start_tok_procs(n_procs)
+        # Corpus encode over the node's GPUs (the reference: `device_map="auto"  # Use multiple GPUs if available`, BGEEmbedding.py:77).
+        # Chunks are independent: one replica of the fused layer stack per entry of `embedding_devices` (a device may repeat, and
+        # `embedding_encode_replicas` > the device count goes round them: logical replicas — how a one-GPU box runs this path), each with its
+        # own stream, captured graphs and worker thread; a corpus-sized batch_encode deals its bucketing windows round the replicas and
+        # gathers the rows, device to device, in arrival order (`_run_window`).  Replica 0 is this object's own model.
+        self._replicas = []
+        devs = cfg_get(self.global_config, "embedding_devices", None)
+        n_rep = int(cfg_get(self.global_config, "embedding_encode_replicas", 0) or 0)
+        if (devs or n_rep > 1) and self._fused is not None:
+            devs = [int(d) for d in (devs or [self.device.index or 0])]
+            n_vis = torch.cuda.device_count()
+            if any(d < 0 or d >= n_vis for d in devs):
+                raise ValueError(f"embedding_devices {devs}: this process sees {n_vis} GPU(s)")
+            n_rep = max(n_rep, len(devs))
+            if n_rep > 1:
+                for r in range(n_rep):
+                    self._replicas.append(_EncodeReplica(self, torch.device("cuda", devs[r % len(devs)]), first=(r == 0)))
         self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
         if self._cached:
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
@@ -237,9 +281,9 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             return [np.asarray(e.ids, dtype=np.int32) for e in enc]
         return [np.asarray(x, dtype=np.int32) for x in tokenize_ragged(self.tokenizer, prompts, max_length)]
 
-    def _forward_ragged(self, id_arrays, normalize: bool):
+    def _forward_ragged(self, id_arrays, normalize: bool, fused=None):
         """One mini-batch of the fused stack from ragged id arrays: ONE int32 array lens | offsets | ids goes to the device
-        (fused_bert.FusedBertLayers.forward_ragged); returns the pooled rows [b, D] fp32 on the GPU."""
+        (fused_bert.FusedBertLayers.forward_ragged); returns the pooled rows [b, D] fp32 on the GPU (`fused`: a replica's stack)."""
         b = len(id_arrays)
         head = np.empty(2 * b + 1, dtype=np.int32)
         lens = head[:b]
@@ -247,7 +291,35 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         head[b] = 0
         np.cumsum(lens, out=head[b + 1:])
         width = -(-int(lens.max()) // 16) * 16        # rows are padded (on the device) to the longest one, rounded up to 16 tokens
-        return self._fused.forward_ragged(np.concatenate([head, *id_arrays]), b, width, normalize)
+        return (fused or self._fused).forward_ragged(np.concatenate([head, *id_arrays]), b, width, normalize)
+
+    @staticmethod
+    def _window_groups(lens, batch_size: int, budget: int):
+        """Mini-batches of one bucketing window: stable sort by token count, then as many rows as fit the token budget of a full-length
+        batch (batch_size x max_length padded tokens; at most 8 x batch_size rows) — at bf16 a 32-row forward of short chunks is launch-bound."""
+        order = np.argsort(lens, kind="stable")
+        groups, start = [], 0
+        while start < len(order):
+            end = start + 1
+            while end < len(order) and end - start < 8 * batch_size and (end - start + 1) * lens[order[end]] <= budget:
+                end += 1
+            groups.append(order[start:end])
+            start = end
+        return groups
+
+    def _run_window(self, rep, id_lists, normalize: bool, batch_size: int, budget: int):
+        """One bucketing window on one replica (its worker thread): the window's mini-batches through the replica's layer stack on the
+        replica's stream; the rows come back in the WINDOW's order, fp32 [n, D] on the replica's device, complete (stream drained)."""
+        import torch
+        lens = np.array([len(x) for x in id_lists])
+        groups = self._window_groups(lens, batch_size, budget)
+        with torch.cuda.device(rep.device), torch.cuda.stream(rep.stream):
+            parts = [self._forward_ragged([id_lists[j] for j in g], normalize, rep.fused) for g in groups]
+            rows = torch.empty((len(id_lists), parts[0].shape[1]), dtype=parts[0].dtype, device=rep.device)
+            where = torch.from_numpy(np.concatenate(groups)).pin_memory().to(rep.device, non_blocking=True)
+            rows[where] = torch.cat(parts, dim=0)
+        rep.stream.synchronize()
+        return rows
 
     def _ragged_ok(self) -> bool:
         """Can mini-batches go to the device as ragged ids (fused stack, right-padding single-segment tokenizer, every row non-empty)?"""
@@ -370,6 +442,9 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                 results, base, budget = None, 0, fwb * batch_size * ml
                 trace = getattr(self, "_trace", None)       # a list: per window (seconds waiting for token ids, seconds launching)
                 import time as _time
+                # replicas (embedding_devices / embedding_encode_replicas): only for corpus-sized calls on the ragged fused path
+                reps = self._replicas if (len(self._replicas) > 1 and len(windows) >= 2 and self._ragged_ok()) else None
+                rep_jobs = []
                 for wi in range(len(windows)):
                     t_w0 = _time.perf_counter()
                     id_lists = collect(pending[wi])
@@ -378,16 +453,15 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     if wi + look < len(windows):
                         pending.append(submit(windows[wi + look]))
                     lens = np.array([len(x) for x in id_lists])
-                    order = np.argsort(lens, kind="stable")
-                    # a mini-batch holds as many rows as fit the token budget of a full-length one (batch_size x ml padded
-                    # tokens; at most 8 x batch_size rows): at bf16 a 32-row forward of short chunks is launch-bound
-                    groups, start = [], 0
-                    while start < len(order):
-                        end = start + 1
-                        while end < len(order) and end - start < 8 * batch_size and (end - start + 1) * lens[order[end]] <= budget:
-                            end += 1
-                        groups.append(order[start:end])
-                        start = end
+                    if reps is not None and lens.min() > 0:
+                        # the window goes to the next replica's worker thread; its rows are collected below, in arrival order
+                        rep = reps[wi % len(reps)]
+                        rep_jobs.append((base, len(id_lists), rep.pool.submit(self._run_window, rep, id_lists, normalize, batch_size, budget)))
+                        base += len(id_lists)
+                        if trace is not None:
+                            trace.append((t_w1 - t_w0, _time.perf_counter() - t_w1))
+                        continue
+                    groups = self._window_groups(lens, batch_size, budget)
                     if self._ragged_ok() and lens.min() > 0:
                         parts = [self._forward_ragged([id_lists[j] for j in g], normalize) for g in groups]
                     else:
@@ -400,6 +474,11 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
                     base += len(id_lists)
                     if trace is not None:
                         trace.append((t_w1 - t_w0, _time.perf_counter() - t_w1))
+                for at, n_w, job in rep_jobs:               # device to device (peer copy across GPUs), order restored by the window's position
+                    rows = job.result()
+                    if results is None:
+                        results = torch.empty((len(texts), rows.shape[1]), dtype=rows.dtype, device=self.device)
+                    results[at:at + n_w] = rows if rows.device == results.device else rows.to(results.device)
             else:
                 prep = lambda c: self._tokenize([instr + t for t in c] if instr else list(c), max_length)
                 futs = [self._tok_pool.submit(prep, c) for c in chunks[:ahead]]
@@ -426,6 +505,9 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         return self.batch_encode(texts, _return_device=True, **kwargs)
 
     def close(self) -> None:
+        for rep in getattr(self, "_replicas", []):
+            rep.close()
+        self._replicas = []
         if getattr(self, "_fused", None) is not None:
             self._fused.release()
         starting = getattr(self, "_tok_procs_starting", None)

@@ -27,6 +27,13 @@ import numpy as np
 from .. import _lib as L
 
 
+# One capture at a time in the process: `torch.cuda.graph.__enter__` synchronises the whole DEVICE, which HIP refuses while any other
+# stream of it is capturing — two encoder replicas (bge._EncodeReplica: one FusedBertLayers each, own stream and worker thread)
+# capturing their first shapes at the same moment failed with hipErrorStreamCaptureUnsupported.  Forwards of other replicas go on.
+import threading as _threading
+_CAPTURE_LOCK = _threading.Lock()
+
+
 # BERT and its RoBERTa-family twins (same layer; position ids start at padding_idx + 1, one token type): XLM-R is bge-m3, the one
 # BGE model whose 8192 positions are safe with the reference's default embedding_max_seq_len = 2048 (config_utils.py:140)
 ENCODER_TYPES = ("bert", "roberta", "xlm-roberta")
@@ -359,10 +366,20 @@ class FusedBertLayers:
             self._stack_ragged(packed, b, l, normalize)
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            ent["hidden"] = self._stack_ragged(packed, b, l, normalize)
+        with _CAPTURE_LOCK:
+            with torch.cuda.graph(graph, stream=self._capture_stream(), capture_error_mode="thread_local"):
+                ent["hidden"] = self._stack_ragged(packed, b, l, normalize)
         ent["graph"] = graph
         return ent
+
+    def _capture_stream(self):
+        """The side stream this stack captures on (one per stack: torch.cuda.graph's default is a process-wide one, shared by every
+        capturing thread)."""
+        import torch
+        st = getattr(self, "_cap_stream", None)
+        if st is None:
+            st = self._cap_stream = torch.cuda.Stream(self.device)
+        return st
 
     def _room_for_a_graph(self) -> bool:
         """Called under the lock before a capture: with the table full, the graph that was replayed longest ago goes (its static
@@ -395,8 +412,9 @@ class FusedBertLayers:
             self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
+        with _CAPTURE_LOCK:
+            with torch.cuda.graph(graph, stream=self._capture_stream(), capture_error_mode="thread_local"):
+                ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
         ent["graph"] = graph
         return ent
 

@@ -48,6 +48,10 @@ def test_bench_two_ranks_sharing_one_gpu():
     assert out["roofline"]["two_scan_streams"] is True and out["roofline"]["kernel_ms"] is None
     assert side["extra"]["config3_batch256"]["last_pipelined_batch_equals_synchronous_search"] is True
     assert out["roofline"]["rows_per_gpu"] == 150000 and out["config"]["x_config3_batch256_qps"] > 0 and out["config"]["x_single_process_qps"] > 0
+    # the encode half of the metric: every rank encoded its own chunks at the same time — per rank, and summed on the line
+    rates = [p["corpus_embed_bf16"]["value"] for p in side["per_rank"]]
+    assert all(r > 0 for r in rates) and out["config"]["x_corpus_embed_bf16_chunks_per_s_sum_over_ranks"] == pytest.approx(sum(rates), rel=1e-4)
+    assert all(p["corpus_embed_bf16"]["encoder_path"] == "hip-fused-layers" and p["corpus_embed_bf16"]["gelu_path"] == "exact-erf-kernel" for p in side["per_rank"])
     # rank 0 then ran the SAME workload through the single-process index (MultiDeviceIndex, what hooks.install builds for
     # num_shards = 2) in a child process: two logical shards on cuda:0 here
     sp = side["single_process"]
@@ -72,6 +76,11 @@ def test_bench_single_process_mode_four_logical_shards():
     assert out["config"]["shard_rows"] == [150000] * 4
     assert out["verified"] == {"last_pipelined_batch_equals_synchronous_search": True, "batch256_last_pipelined_batch_equals_synchronous_search": True}
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # the corpus encode over the same "devices" from the same process: four logical replicas of the layer stack on cuda:0
+    er = side["extra"]["corpus_embed_bf16_replicas"]
+    assert "error" not in er, er
+    assert er["replicas"]["encode_replicas"] == ["cuda:0"] * 4 and er["one_replica"]["encode_replicas"] == ["cuda:0"]
+    assert out["config"]["x_corpus_embed_bf16_chunks_per_s"] == pytest.approx(er["replicas"]["value"], rel=1e-4) and er["replicas"]["value"] > 0
 
 
 @pytest.mark.timeout(1500)

@@ -205,9 +205,11 @@ def test_both_gelu_paths_on_heavy_tailed_pre_activations_at_bert_base_depth(dtyp
     """The exactness gate of the opt-in epilogue path.  Real BGE weights are not in the image, and seed-initialised
     BERT pre-activations are near-Gaussian with |x| < 4 — so the FFN-up rows of a 12-layer BERT-base shape get log-normal scales
     (a scale mixture over the units) until the pre-activations of EVERY layer are heavy-tailed (kurtosis >> 3, |x| beyond 8,
-    a good share of them in the 2 <= |x| <= 3.5 band where the tanh and erf forms of GELU differ most).  Both paths are held to
-    min row cosine >= 0.9995 and every pairwise score within 5e-4 of the fp32 oracle (erf form, BGEEmbedding.py:119-120); the default
-    must be the exact one."""
+    a good share of them in the 2 <= |x| <= 3.5 band where the tanh and erf forms of GELU differ most).  Bars against the fp32 oracle
+    (erf form, BGEEmbedding.py:119-120): fp16 — min row cosine >= 0.9995, every pairwise score within 5e-4, both paths; bf16 — activations
+    of magnitude 30-45 carry 8 mantissa bits, the EXACT path itself sits at 0.9992 / 1.9e-3 here (measured), so the bar is the dtype's:
+    0.999 / 3e-3; and in both dtypes the epilogue path may be no further from the oracle than the exact path by more than 2e-4 in cosine /
+    3e-4 in any pairwise score, the two paths' rows within 0.9995 of each other.  The default must be the exact one."""
     import torch
     from comorag_amd.embedding_model import _get_embedding_model_class
     from comorag_amd.utils.config_utils import BaseConfig
@@ -239,7 +241,7 @@ def test_both_gelu_paths_on_heavy_tailed_pre_activations_at_bert_base_depth(dtyp
         band = float(((x.abs() >= 2.0) & (x.abs() <= 3.5)).double().mean())
         assert kurt > 6.0 and float(x.abs().max()) >= 8.0 and band > 0.05, (kurt, float(x.abs().max()), band)
     cls = _get_embedding_model_class("bge-tiny-random")
-    rep = {}
+    rep, rows = {}, {}
     for mode in ("exact", "epilogue"):
         cfg = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=8, embedding_max_seq_len=128, embedding_model_dtype=dtype, embedding_gelu=mode)
         em = cls(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
@@ -249,10 +251,14 @@ def test_both_gelu_paths_on_heavy_tailed_pre_activations_at_bert_base_depth(dtyp
         em.close()
         w64 = want.astype(np.float64)
         rep[mode] = (path, float((got * w64).sum(1).min()), float(np.abs(got @ got.T - w64 @ w64.T).max()))
+        rows[mode] = got
     print("heavy-tailed GELU gate", dtype, rep)
     assert rep["exact"][0] == "exact-erf-kernel"
+    cos_bar, pair_bar = {"bfloat16": (0.999, 3e-3), "float16": (0.9995, 5e-4)}[dtype]
     for mode, (path, cos, pair) in rep.items():
-        assert cos >= 0.9995 and pair <= 5e-4, (mode, path, cos, pair)
+        assert cos >= cos_bar and pair <= pair_bar, (mode, path, cos, pair)
+    assert rep["epilogue"][1] >= rep["exact"][1] - 2e-4 and rep["epilogue"][2] <= rep["exact"][2] + 3e-4, rep
+    assert float((rows["epilogue"] * rows["exact"]).sum(1).min()) >= cos_bar
 
 
 def test_fused_forward_launches_no_gelu_kernel():
@@ -432,3 +438,41 @@ def test_ragged_mini_batches_equal_padded_ones(kind):
             fz.forward_ragged(short, 2, width, True)
     assert len(fz._graphs) == 4 and (2, 80, "ragged", True) in fz._graphs and (2, 16, "ragged", True) not in fz._graphs
     fz.release()
+
+
+@pytest.mark.parametrize("replicas", [2, 4])
+def test_corpus_encode_over_replicas_equals_the_single_replica_rows(replicas):
+    """`embedding_devices` / `embedding_encode_replicas` (the reference's `device_map="auto"  # Use multiple GPUs if available`,
+    BGEEmbedding.py:77): one copy of the fused layer stack per replica, each on its own stream and worker thread, the bucketing windows
+    of a corpus-sized batch_encode dealt round them, rows gathered device to device in arrival order.  Rehearsal on the one GPU of a
+    test box: R logical replicas on cuda:0 must return the rows of the single-replica path BIT FOR BIT (same windows, same mini-batches,
+    same kernels), through batch_encode and batch_encode_dev, twice (captured graphs on the second pass), and a query-sized call must not
+    touch the replicas."""
+    import torch
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.utils.config_utils import BaseConfig
+    model, tok = _peaked_tiny_bert(torch.bfloat16)
+    texts = [f"the prince and the golden slipper number {i} " + "and the bird in the tree " * (i % 11) + "midnight " * (i % 3) for i in range(203)]
+    cls = _get_embedding_model_class("bge-tiny-random")
+    def make(**kw):
+        cfg = BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=8, embedding_max_seq_len=128, embedding_model_dtype="bfloat16", **kw)
+        return cls(global_config=cfg, embedding_model_name=cfg.embedding_model_name, model=copy.deepcopy(model), tokenizer=tok)
+    one = make()
+    want = one.batch_encode(texts)
+    many = make(embedding_devices=[0], embedding_encode_replicas=replicas)
+    assert len(one._replicas) == 0 and len(many._replicas) == replicas and many._replicas[0].fused is many._fused
+    assert len({id(r.fused) for r in many._replicas}) == replicas and len({r.stream.cuda_stream for r in many._replicas}) == replicas
+    for rep in range(2):
+        got = many.batch_encode(texts)
+        assert got.shape == want.shape and np.array_equal(got, want), (rep, float(np.abs(got - want).max()))
+    dev = many.batch_encode_dev(texts[:77])
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), one.batch_encode(texts[:77]))
+    # every replica did work; a single query stays on the owner's stack
+    assert all(len(r.fused._seen) + len(r.fused._graphs) > 0 for r in many._replicas)
+    seen = [dict(r.fused._seen) for r in many._replicas[1:]]
+    np.testing.assert_array_equal(many.batch_encode("midnight"), one.batch_encode("midnight"))
+    assert seen == [dict(r.fused._seen) for r in many._replicas[1:]]
+    with pytest.raises(ValueError):
+        make(embedding_devices=[torch.cuda.device_count()])
+    one.close(); many.close()
+    assert many._replicas == []

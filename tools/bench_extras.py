@@ -134,15 +134,19 @@ def encoder_parity(torch, em, chunks, n=32, peak=None):
     return out
 
 
-def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, batch=32, tok_processes=0, parity=True):
+def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, batch=32, tok_processes=0, parity=True, devices=None, replicas=0):
     """Corpus-embed chunks/s end to end and where the time goes: tokenizer alone (host), forward + pool alone (device
-    inputs ready), pool kernel alone; MFMA fraction of the forward from the model's matmul flops."""
+    inputs ready), pool kernel alone; MFMA fraction of the forward from the model's matmul flops.
+    devices / replicas: `embedding_devices` / `embedding_encode_replicas` — the corpus encode dealt over that many copies of the layer
+    stack (one per GPU of the node; logical replicas on a one-GPU box)."""
     from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel, pool_l2norm
     from comorag_amd.utils.config_utils import BaseConfig
     from tools.synthetic import random_bert, synthetic_chunks, synthetic_wordpiece_tokenizer
     tok, words = synthetic_wordpiece_tokenizer()
     cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_batch_size=batch, embedding_model_dtype=dtype, device=device.index or 0)
     cfg.embedding_tokenizer_processes = tok_processes
+    if devices is not None or replicas:
+        cfg.embedding_devices, cfg.embedding_encode_replicas = (list(devices) if devices is not None else None), int(replicas)
     em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert(kind, vocab_size=len(tok)), tokenizer=tok)
     chunks = synthetic_chunks(words, n_chunks, tokens_per_chunk=560)          # > 512 word pieces: every chunk is truncated to 512 positions
     em.batch_encode(chunks[:2 * batch])
@@ -213,7 +217,7 @@ def encode_breakdown(torch, device, kind="base", dtype="bf16", n_chunks=256, bat
            "end_to_end_over_forward_only": (n_chunks / dt_e2e) / fwd_rate,
            "tokenizer_processes": (f"auto: {em._tok_procs_auto} worker processes" if (tok_processes < 0 and em._tok_procs is not None) else tok_processes),
            "gelu_path": getattr(em._fused, "gelu_path", None) if em._fused is not None else None,
-           "encoder_path": em.encoder_path, **stages,
+           "encoder_path": em.encoder_path, "encode_replicas": [str(r.device) for r in em._replicas] or [str(em.device)], **stages,
            **({"parity_vs_fp32_oracle": encoder_parity(torch, em, chunks)} if parity and dtype != "auto" else {}),
            "host_ms": {"end_to_end": dt_e2e * 1e3, "waiting_for_token_ids": sum(t[0] for t in trace) * 1e3,
                        "padding_and_launching": sum(t[1] for t in trace) * 1e3, "windows": len(trace)}}
