@@ -27,11 +27,44 @@ import numpy as np
 from .. import _lib as L
 
 
-# One capture at a time in the process: `torch.cuda.graph.__enter__` synchronises the whole DEVICE, which HIP refuses while any other
-# stream of it is capturing — two encoder replicas (bge._EncodeReplica: one FusedBertLayers each, own stream and worker thread)
-# capturing their first shapes at the same moment failed with hipErrorStreamCaptureUnsupported.  Forwards of other replicas go on.
+# Graph captures are exclusive in the process — against each other AND against every other thread's forward launches:
+#   * `torch.cuda.graph.__enter__` synchronises the whole DEVICE, which HIP refuses while another stream of it is capturing (two encoder
+#     replicas — bge._EncodeReplica: one FusedBertLayers each, own stream and worker thread — capturing their first shapes at the same
+#     moment: hipErrorStreamCaptureUnsupported);
+#   * a forward launched EAGERLY by another thread meanwhile may be hipBLASLt's first call for its shape, and that call touches the
+#     legacy stream: "operation would make the legacy stream depend on a capturing blocking stream" (hipblaslt.cpp:172), the GEMM fails,
+#     the process dies in Tensile's initialisation (seen in bench.py --single-process: four replicas behind an index's blocking streams).
+# Forwards hold the gate shared while they ENQUEUE (host side only: the GPU work of other streams runs on during a capture).
 import threading as _threading
-_CAPTURE_LOCK = _threading.Lock()
+
+
+class _Gate:
+    def __init__(self):
+        self._cv, self._readers, self._writer = _threading.Condition(), 0, False
+
+    class _Hold:
+        def __init__(self, gate, exclusive): self.g, self.x = gate, exclusive
+        def __enter__(self):
+            g = self.g
+            with g._cv:
+                if self.x:
+                    while g._writer or g._readers: g._cv.wait()
+                    g._writer = True
+                else:
+                    while g._writer: g._cv.wait()
+                    g._readers += 1
+        def __exit__(self, *exc):
+            g = self.g
+            with g._cv:
+                if self.x: g._writer = False
+                else: g._readers -= 1
+                g._cv.notify_all()
+
+    def shared(self): return _Gate._Hold(self, False)
+    def exclusive(self): return _Gate._Hold(self, True)
+
+
+_GATE = _Gate()
 
 
 # BERT and its RoBERTa-family twins (same layer; position ids start at padding_idx + 1, one token type): XLM-R is bge-m3, the one
@@ -302,23 +335,26 @@ class FusedBertLayers:
                             self._seen.clear()
                         seen = self._seen[key] = self._seen.get(key, 0) + 1
                         if seen >= 2 and self._room_for_a_graph():
-                            ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None, pool)
+                            with _GATE.exclusive():
+                                ent = self._graphs[key] = self._capture(b, l, token_type_ids is not None, pool)
                     if ent is not None:
-                        cur = torch.cuda.current_stream(input_ids.device)
-                        if ent.get("stream") is not None and ent["stream"] != cur:
-                            cur.wait_stream(ent["stream"])          # a caller on another stream: order behind the last reader of the buffers
-                        ent["stream"] = cur
-                        self._touch(ent)
-                        ent["ids"].copy_(input_ids, non_blocking=True)
-                        ent["lens"].copy_(lens_src, non_blocking=True)
-                        if token_type_ids is not None:
-                            ent["tt"].copy_(token_type_ids, non_blocking=True)
-                        ent["graph"].replay()
-                        if pool is not None:
-                            return ent["hidden"].clone()         # [b, hidden] fp32: the graph's static output, copied out under the lock
-                        return consume(ent["hidden"]) if consume is not None else ent["hidden"].clone()
-            hidden = self._stack(input_ids, lens_src.to(input_ids.device, non_blocking=True), token_type_ids, pool)
-            return hidden if pool is not None else (consume(hidden) if consume is not None else hidden)
+                        with _GATE.shared():
+                            cur = torch.cuda.current_stream(input_ids.device)
+                            if ent.get("stream") is not None and ent["stream"] != cur:
+                                cur.wait_stream(ent["stream"])          # a caller on another stream: order behind the last reader of the buffers
+                            ent["stream"] = cur
+                            self._touch(ent)
+                            ent["ids"].copy_(input_ids, non_blocking=True)
+                            ent["lens"].copy_(lens_src, non_blocking=True)
+                            if token_type_ids is not None:
+                                ent["tt"].copy_(token_type_ids, non_blocking=True)
+                            ent["graph"].replay()
+                            if pool is not None:
+                                return ent["hidden"].clone()         # [b, hidden] fp32: the graph's static output, copied out under the lock
+                            return consume(ent["hidden"]) if consume is not None else ent["hidden"].clone()
+            with _GATE.shared():
+                hidden = self._stack(input_ids, lens_src.to(input_ids.device, non_blocking=True), token_type_ids, pool)
+                return hidden if pool is not None else (consume(hidden) if consume is not None else hidden)
 
     def forward_ragged(self, packed_host: np.ndarray, b: int, l: int, normalize: bool = True):
         """One mini-batch from the tokenizer's ragged output: packed_host = int32 [lens (b) | offsets (b + 1) | token ids back to
@@ -340,17 +376,20 @@ class FusedBertLayers:
                             self._seen.clear()
                         seen = self._seen[key] = self._seen.get(key, 0) + 1
                         if seen >= 2 and self._room_for_a_graph():
-                            ent = self._graphs[key] = self._capture_ragged(b, l, bool(normalize))
+                            with _GATE.exclusive():
+                                ent = self._graphs[key] = self._capture_ragged(b, l, bool(normalize))
                     if ent is not None:
-                        cur = torch.cuda.current_stream(self.device)
-                        if ent.get("stream") is not None and ent["stream"] != cur:
-                            cur.wait_stream(ent["stream"])
-                        ent["stream"] = cur
-                        self._touch(ent)
-                        ent["packed"][:n].copy_(src, non_blocking=True)
-                        ent["graph"].replay()
-                        return ent["hidden"].clone()
-            return self._stack_ragged(src.to(self.device, non_blocking=True), b, l, bool(normalize))
+                        with _GATE.shared():
+                            cur = torch.cuda.current_stream(self.device)
+                            if ent.get("stream") is not None and ent["stream"] != cur:
+                                cur.wait_stream(ent["stream"])
+                            ent["stream"] = cur
+                            self._touch(ent)
+                            ent["packed"][:n].copy_(src, non_blocking=True)
+                            ent["graph"].replay()
+                            return ent["hidden"].clone()
+            with _GATE.shared():
+                return self._stack_ragged(src.to(self.device, non_blocking=True), b, l, bool(normalize))
 
     def _capture_ragged(self, b: int, l: int, normalize: bool):
         import torch
@@ -366,9 +405,8 @@ class FusedBertLayers:
             self._stack_ragged(packed, b, l, normalize)
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with _CAPTURE_LOCK:
-            with torch.cuda.graph(graph, stream=self._capture_stream(), capture_error_mode="thread_local"):
-                ent["hidden"] = self._stack_ragged(packed, b, l, normalize)
+        with torch.cuda.graph(graph, stream=self._capture_stream(), capture_error_mode="thread_local"):
+            ent["hidden"] = self._stack_ragged(packed, b, l, normalize)
         ent["graph"] = graph
         return ent
 
@@ -412,9 +450,8 @@ class FusedBertLayers:
             self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
         cur.wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with _CAPTURE_LOCK:
-            with torch.cuda.graph(graph, stream=self._capture_stream(), capture_error_mode="thread_local"):
-                ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
+        with torch.cuda.graph(graph, stream=self._capture_stream(), capture_error_mode="thread_local"):
+            ent["hidden"] = self._stack(ent["ids"], ent["lens"], ent["tt"], pool)
         ent["graph"] = graph
         return ent
 
