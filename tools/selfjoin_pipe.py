@@ -20,7 +20,10 @@ idx = DenseIndex(dim, dtype, capacity_hint=E, options=opts); idx.append_dev(x); 
 ids_t = torch.empty((E, K), dtype=torch.int64, device=dev); sc_t = torch.empty((E, K), dtype=torch.float32, device=dev)
 flops = 2.0 * E * E * dim
 ref = None
-for mode, blk in (("one stream", 1024), ("pipelined", 1000), ("pipelined", 1024), ("pipelined", 2048), ("pipelined", 4096), ("pipelined", 8192), ("one stream", 4096)):
+routes = [("one stream", 1024), ("pipelined", 1000), ("pipelined", 1024), ("pipelined", 2048), ("pipelined", 4096), ("pipelined", 8192), ("one stream", 4096)]
+if os.environ.get("SJ_ROUTES"):
+    routes = [(("pipelined" if r[0] == "p" else "one stream"), int(r[1:])) for r in os.environ["SJ_ROUTES"].split(",")]
+for mode, blk in routes:
     best = None
     for rep in range(3):
         ids_t.fill_(-7); torch.cuda.synchronize()
