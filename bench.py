@@ -931,6 +931,7 @@ def main():
                 "config4_call_frac_of_hbm": _get(extra, "config4_probe_loop", "frac"),
                 "f1_selfjoin_bf16_s": _get(extra, "f1_synonymy_selfjoin", "bf16", "threshold_search_whole_join_s"),
                 "f1_selfjoin_bf16_frac_of_2500TF": _get(extra, "f1_synonymy_selfjoin", "bf16", "frac"),
+                "f1_selfjoin_bf16_ids_download_s": _get(extra, "f1_synonymy_selfjoin", "bf16", "ids_download_s"),
                 "f4_ppr_comorag_scale_us": _get(extra, "f4_dpr_seeded_ppr", "comorag_scale", "fused_us_per_query"),
                 "f4_ppr_1M_passages_us": _get(extra, "f4_dpr_seeded_ppr", "at_1M_passages", "fused_us_per_query"),
                 "attention_us_per_layer_bf16": _get(extra, "corpus_embed_bf16", "attention_us_per_layer"),

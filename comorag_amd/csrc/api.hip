@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <shared_mutex>
@@ -88,6 +90,17 @@ struct Workspace {
     // one copy each way — five pageable D2H copies cost more than the search of a small corpus
     DevBuf d_pack;
     int* flag_ptr = nullptr;     // the non-finite-query flag the kernels set: flag.p, or the head of d_pack for the host API
+    // Synchronous host API with mapped results: the word (device view of the pinned buffer, bytes 4..7) that the search's LAST kernel sets
+    // once its results are written — 1: final, 2: the finishing stage overflowed and the merge recorded in `lazy` is still due.  Offered by
+    // cmr_index_search_begin; a route that can honour it (single-launch search, scan with the finishing stage) sets done_used, and
+    // cmr_index_search_finish then polls the word instead of waiting for the stream (5.5 us per call: tools/probe/poll_probe.hip).
+    int* done_ptr = nullptr;
+    bool done_used = false;
+    struct LazyMerge {
+        bool due = false;
+        const u64* lists = nullptr; const int* cnt = nullptr; int W = 0, NQ = 0, cap = 0, nqp = 0, k = 0; const float2* mm = nullptr; long long id_base = 0;
+        int64_t* ids = nullptr; float* scores = nullptr; float* mn = nullptr; float* mx = nullptr; const int* state = nullptr;
+    } lazy;
     void* h_pin = nullptr;
     void* h_pin_dev = nullptr;   // the same buffer as the device sees it (mapped, fine-grained)
     size_t h_pin_cap = 0;
@@ -179,6 +192,7 @@ struct cmr_index {
     int wide_mode = 0;       // wide_mode: batches of more than one narrow pass — 1: the register-resident wide kernel, 2: the query-split grid of the
                              // narrow kernel (up to 4 query tiles walk the same panel ranges on CUs of one XCD; any dim / dtype), 0: the measured default
     int tau_in_scan = 1;     // sample_tau_in_scan = 0: the single sampling level of a small batch is merged by a launch of its own again
+    int sync_poll = 1;       // sync_poll = 0: the synchronous host API waits for the stream instead of polling the done word of its mapped result buffer
     int scan_fin = 1;        // scan_fin = 0: small synchronous batches on corpora beyond the single-launch path run the sampling / scan / merge chain
                              // instead of the scan with the finishing stage (thresholds and final selection inside the scan launch)
     int fin_dense = 16384;   // scan_fin_dense: keys per query of the finishing stage's dense candidate lists (~k x panels / 1024 beat a threshold taken
@@ -226,6 +240,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "sample_single_max") idx->single_level_max = std::max<long long>(0, v);
     else if (n == "sample_tau_in_scan") idx->tau_in_scan = (int)v;
     else if (n == "scan_fin") idx->scan_fin = (int)v;
+    else if (n == "sync_poll") idx->sync_poll = (int)v;
     else if (n == "scan_fin_dense") idx->fin_dense = (int)std::max<long long>(1, std::min<long long>(v, 1 << 16));
     else if (n == "scan_fin_spin") idx->fin_spin = (int)std::max<long long>(0, std::min<long long>(v, 1000));
     else if (n == "scan_fin_queries") idx->fin_max_q = (int)std::max<long long>(1, std::min<long long>(v, CMR_FIN_MAX_QUERIES));
@@ -249,7 +264,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 // development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
-                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "sync_poll", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "sample_div", "sample_maxmul", "pipe_reserve_cus",
                                   "pipe_slots", "wide_waves", "wide_mode", "stream_nt", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
@@ -645,6 +660,9 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         a.fin_spin = idx->fin_spin;
         a.out_ids = ids_dev; a.out_scores = scores_dev; a.out_min = min_dev; a.out_max = max_dev; a.id_base = kernel_id_base(idx);
         fin_state = (const int*)ws->fin_ctl.p + CMR_FIN_STATE;
+        // the synchronous host API (results in its mapped buffer, nothing to remap behind the scan): the kernel reports its state in the
+        // caller's done word and the merge launch — which would return in its first instruction on state 1 — is issued only on state 2
+        if (ws->done_ptr && idx->blk_local.size() <= 1) a.fin_done = ws->done_ptr;
     }
     HIP_TRY(wide ? cmr_launch_scan_wide(g, a, sm) : fin ? cmr_launch_scan_fin(g, a, sm) : cmr_launch_scan_topk(g, a, sm));
     if (prof) {
@@ -652,6 +670,14 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         std::lock_guard<std::mutex> pg(idx->prof_mu);
         idx->prof_events.push_back(pe);
         idx->prof_bytes = algorithmic_bytes(idx, nqp, k);
+    }
+    if (a.fin_done) {
+        ws->lazy.due = true;
+        ws->lazy.lists = (const u64*)ws->lists.p; ws->lazy.cnt = (const int*)ws->cnt.p; ws->lazy.W = W; ws->lazy.NQ = NQ; ws->lazy.cap = g.cap; ws->lazy.nqp = nqp; ws->lazy.k = k;
+        ws->lazy.mm = (const float2*)ws->mm.p; ws->lazy.id_base = kernel_id_base(idx); ws->lazy.ids = ids_dev; ws->lazy.scores = scores_dev; ws->lazy.mn = min_dev; ws->lazy.mx = max_dev;
+        ws->lazy.state = fin_state;
+        ws->done_used = true;
+        return CMR_OK;
     }
     if (sq != sm) {   // pipelined: the candidate merge leaves the scan stream so the next main scan starts at once
         HIP_TRY(hipEventRecord(ev_scan, sm));
@@ -717,7 +743,9 @@ int search_enqueue(cmr_index* idx, Workspace* ws, const float* q_dev, int nq, in
             HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), ws->stream));
         }
         HIP_TRY(cmr_launch_tiny_search(idx->dtype, idx->corpus, q_dev, nq, idx->dim, idx->dpad, idx->n, k, kernel_id_base(idx), ws->d_out.p,
-                                       ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, idx->small_max_panels, ws->stream));
+                                       ids_dev, scores_dev, min_dev, max_dev, ws->flag_ptr, idx->tiny_multi ? (int*)ws->arrive.p : nullptr, idx->small_max_panels, ws->stream,
+                                       (ws->done_ptr && idx->blk_local.size() <= 1) ? ws->done_ptr : nullptr));
+        if (ws->done_ptr && idx->blk_local.size() <= 1) ws->done_used = true;
         return remap_ids_enqueue(idx, ids_dev, (long long)nq * k, ws->stream);
     }
     const int narrow = (nq > 32 && max_nqt >= 2) ? 64 : 32;
@@ -1376,6 +1404,7 @@ struct CmrPending {
     Workspace* ws = nullptr;
     bool locked = false;          // holds idx->mu shared (released by finish / abandon ON THE SAME THREAD)
     bool mapped = false;          // results land in the pinned buffer by themselves (zero-copy) / by the enqueued D2H copy
+    bool poll = false;            // the search's last kernel sets the done word of the pinned buffer (Workspace::done_ptr): finish polls it
     int nq = 0, k = 0;
     size_t o_ids = 0, o_sc = 0, o_min = 0, o_max = 0;
 };
@@ -1428,9 +1457,12 @@ int cmr_index_search_begin(cmr_index_t* idx, const float* q, int nq, int k, cons
             }
             int* const dev_flag = ws->flag_ptr;
             ws->flag_ptr = (int*)d;
+            ws->done_ptr = idx->sync_poll ? (int*)(d + 4) : nullptr; ws->done_used = false; ws->lazy.due = false;      // (bytes 4..7 of the header were zeroed above)
             const int rc_ = search_enqueue(idx, ws, q_in, nq, k, (int64_t*)(d + o_ids), (float*)(d + o_sc), (float*)(d + o_min), (float*)(d + o_max), min_score);
             ws->flag_ptr = dev_flag;
+            ws->done_ptr = nullptr;
             P->mapped = true;
+            P->poll = rc_ == CMR_OK && ws->done_used;
             return rc_;
         }
         // packed device buffer and its pinned host twin, one copy each way; the queries go through the pinned buffer too (a
@@ -1468,7 +1500,30 @@ int cmr_index_search_finish(CmrPending* P, int64_t* out_ids, float* out_scores, 
     int rc = set_device(P->idx->device);
     if (rc) return rc;
     Workspace* ws = P->ws;
-    HIP_TRY(hipStreamSynchronize(ws->stream));
+    if (P->poll) {
+        // the last kernel of the search stores this word behind its results (both in the pinned buffer: the device's writes arrive in
+        // order): seen ~5.5 us before hipStreamSynchronize returns.  Bounded: a launch that never reports (a fault) is left to the stream.
+        volatile int* const w = (volatile int*)((char*)ws->h_pin + 4);
+        int st = *w;
+        if (!st) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spin = 1; !(st = *w); ++spin) {
+                __builtin_ia32_pause();
+                if ((spin & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!st) { HIP_TRY(hipStreamSynchronize(ws->stream)); st = *w; }
+        if (ws->lazy.due && st != 1) {      // a dense list or a staging area of the finishing stage overflowed: the merge works from the per-wave lists
+            const Workspace::LazyMerge& L = ws->lazy;
+            ws->lazy.due = false;
+            HIP_TRY(cmr_launch_merge_query(L.lists, L.cnt, L.W, L.NQ, L.cap, L.nqp, L.k, L.mm, L.id_base, L.ids, L.scores, L.mn, L.mx, nullptr, ws->stream, false, L.state));
+            HIP_TRY(hipStreamSynchronize(ws->stream));
+        }
+        ws->lazy.due = false;
+    } else {
+        HIP_TRY(hipStreamSynchronize(ws->stream));
+    }
     const char* hp = (const char*)ws->h_pin;
     int flagged = 0;
     memcpy(&flagged, hp, sizeof(int));
@@ -1488,6 +1543,7 @@ void cmr_index_search_abandon(CmrPending* P) {
     if (!P) return;
     (void)hipSetDevice(P->idx->device);
     (void)hipStreamSynchronize(P->ws->stream);
+    P->ws->lazy.due = false;
     // a query flagged non-finite leaves its mark in the packed DEVICE buffer of the copy path: clear it for the next call
     if (!P->mapped && P->ws->d_pack.p) (void)hipMemsetAsync(P->ws->d_pack.p, 0, sizeof(int), P->ws->stream);
     pending_release(P);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void prep_queries_kernel(const float* __restric
     bool bad = false;
     const uint4 v = cmr_pack_slot<DT>(qi < nq ? q + (size_t)qi * dim : nullptr, dim, ks, lane, bad);
     qfrag[(size_t)blk * 64 + lane] = v;
-    if (bad) *(volatile int*)flag = 1;     // plain store (every writer writes 1): the flag may live in mapped host memory
+    if (bad) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (every writer writes 1) the flag may live in mapped host memory: visible there before the done word
 }
 
 // tau[i] = (smallest candidate key whose score is >= min_score) - 1, so that key > tau <=> score >= min_score
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void convert_rows_kernel(const float* __restri
     bool bad = false;
     const uint4 v = cmr_pack_slot<DT>(src, dim, ks, lane, bad);
     corpus[((size_t)panel * ks_total + ks) * 64 + lane] = v;
-    if (bad) *(volatile int*)flag = 1;     // plain store (every writer writes 1): the flag may live in mapped host memory
+    if (bad) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (every writer writes 1) the flag may live in mapped host memory: visible there before the done word
     if (shadow && DT != CMR_DT_F32) {
         // fp32 shadow, row-major [*, dim]: this thread owns the same 8 k of the row
         const int k0 = cmr_blk_k<DT == CMR_DT_F32 ? CMR_DT_BF16 : DT>(ks, lane, 0);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
                                                           int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
                                                           float* __restrict__ out_min, float* __restrict__ out_max, int* __restrict__ flag, int stage_raw,
                                                           int* __restrict__ arrive, int ppw, u64* __restrict__ cand, float2* __restrict__ part_mm,
-                                                          float* __restrict__ out_full, long long ld_out) {
+                                                          float* __restrict__ out_full, long long ld_out, int* __restrict__ done) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     __shared__ int ticket;
     __shared__ u64 tiny_stage[8][128];      // per wave: the selection's surviving keys (two per lane for 64 < k <= 128)
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
         const int qi = t * 32 + (l & 31);
         qf[i] = cmr_pack_slot<DT>(qi < nq ? qsrc + (size_t)qi * dim : nullptr, dim, ks, l, bad);
     }
-    if (bad) *(volatile int*)flag = 1;     // plain store (every writer writes 1): the flag may live in mapped host memory
+    if (bad) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (every writer writes 1) the flag may live in mapped host memory: visible there before the done word
     __syncthreads();
     const int ld = npanels * CMR_PANEL_ROWS;
     const v4u* qv = reinterpret_cast<const v4u*>(qf);
@@ -582,9 +582,11 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
     }
     for (int qi = wave; qi < nq; qi += 8) {
         float mn = __builtin_inff(), mx = -__builtin_inff();
+        // (system-scope stores: a synchronous caller polls the done word of its mapped buffer — plain stores are acknowledged before they are
+        // visible to the host, and the word behind s_waitcnt vmcnt(0) would overtake them)
         auto emit = [&](int r, u64 kk) {
-            out_ids[(size_t)qi * k + r] = kk ? (int64_t)cmr_key_row(kk) + id_base : -1;
-            out_scores[(size_t)qi * k + r] = kk ? cmr_key_score(kk) : -__builtin_inff();
+            __hip_atomic_store(&out_ids[(size_t)qi * k + r], kk ? (int64_t)cmr_key_row(kk) + id_base : (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out_scores[(size_t)qi * k + r], kk ? cmr_key_score(kk) : -__builtin_inff(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         };
         if (!hier) {
             tiny_select_stream(nrows < 1024 ? nrows : 1024, k, stage, tiny_carry[wave], lane,
@@ -612,7 +614,15 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
-        if (lane == 0) { if (out_min) out_min[qi] = mn; if (out_max) out_max[qi] = mx; }
+        if (lane == 0) {
+            if (out_min) __hip_atomic_store(&out_min[qi], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (out_max) __hip_atomic_store(&out_max[qi], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (done) {     // a synchronous caller polls this word (mapped host memory) instead of waiting for the end-of-kernel signal: results first
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -621,7 +631,7 @@ size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi, int max_pan
 
 static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
                               void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
-                              int max_panels, float* out_full, long long ld_out, hipStream_t s) {
+                              int max_panels, float* out_full, long long ld_out, hipStream_t s, int* done = nullptr) {
     const int ks = dtype == CMR_DT_F32 ? dpad / 8 : dpad / 16;
     const int npanels = (int)((nrows + CMR_PANEL_ROWS - 1) / CMR_PANEL_ROWS);
     const int nqt = (nq + 31) / 32;
@@ -650,7 +660,7 @@ static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLds); \
         if (e != hipSuccess) return e;                                                                                               \
         hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(g.nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scores, out_ids, \
-                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm, out_full, ld_out);              \
+                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm, out_full, ld_out, out_full ? nullptr : done); \
     }
     switch (dtype) {
         case CMR_DT_BF16: TS(CMR_DT_BF16) break;
@@ -664,9 +674,9 @@ static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int
 
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
                                   void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
-                                  int max_panels, hipStream_t s) {
+                                  int max_panels, hipStream_t s, int* done) {
     return tiny_launch(dtype, corpus, q, nq, dim, dpad, nrows, k, id_base, scratch, out_ids, out_scores, out_min, out_max, flag, arrive, max_panels,
-                       nullptr, 0, s);
+                       nullptr, 0, s, done);
 }
 
 // all raw scores [nq, ld_out] of a small corpus (nq <= 16) in one launch; scratch: nq * npanels * 32 floats

@@ -71,6 +71,10 @@ struct CmrScanArgs {
     float* out_min;
     float* out_max;
     long long id_base;
+    // a word in pinned, device-mapped host memory (or nullptr) that the launch's LAST store sets once the results are written: 1 = final,
+    // 2 = a list overflowed (the merge launch is still due).  The synchronous host API polls it instead of waiting for the end-of-kernel
+    // signal (5.5 us per call on MI355X: tools/probe/poll_probe.hip) and launches the merge only in state 2.
+    int* fin_done;
 };
 // control words (ints) — every counter on a 128-byte line of its own: device atomics on one line serialise
 #define CMR_FIN_DONE 0        // workgroups whose waves have all published their first-panel maxima
@@ -119,7 +123,7 @@ int cmr_tiny_kind(int nq, int npanels, int k, int multi, int max_panels);
 size_t cmr_tiny_scratch_bytes(int nq, int npanels, int k, int multi, int max_panels);
 hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, int k, long long id_base,
                                   void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
-                                  int max_panels, hipStream_t s);
+                                  int max_panels, hipStream_t s, int* done = nullptr);      // done: as CmrScanArgs::fin_done (set to 1 behind the results)
 hipError_t cmr_launch_tiny_scores(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, void* scratch,
                                   float* out, long long ld_out, int* flag, hipStream_t s);
 // per-row top-k (k <= 4096) of a materialised score matrix [nq, ld]

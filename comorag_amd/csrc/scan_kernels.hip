@@ -124,6 +124,7 @@ struct ScanP {
     float* out_min;
     float* out_max;
     long long id_base;
+    int* fin_done;         // mapped host word (or nullptr): the state once more, stored LAST — what a synchronous caller polls
 };
 
 // Slow path, part 1 (inline, a handful of registers, no waits on global memory): push the keys of
@@ -725,40 +726,65 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         __syncthreads();
         if (fin_sh[0] != (int)gridDim.x - 1) return;
         u64* carry = reinterpret_cast<u64*>(smem) + wave * 64;      // the query tile is no longer needed
-        bool over = __hip_atomic_load(&P.fin[CMR_FIN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        // Everything the selection of a query needs is asked for in ONE batch of independent device-scope loads — the overflow word, the
+        // list length, the first 1024 dense keys (speculatively: slots beyond the length hold leftovers of earlier launches and are masked
+        // by index afterwards) and the workgroups' min / max: one round trip to L2 (2.2 us) where the dependent sequence took four.
+        bool over = false;
         for (int q = wave; q < nq_g; q += CMR_SCAN_WAVES) {
-            const int total = __hip_atomic_load(&P.fin[CMR_FIN_DCNT(q)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (total > P.fin_dcap) { over = true; continue; }
             const u64* D = P.fin_dense + (size_t)q * P.fin_dcap;
+            const int over_l = __hip_atomic_load(&P.fin[CMR_FIN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int total_l = __hip_atomic_load(&P.fin[CMR_FIN_DCNT(q)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64 key[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = lane + 64 * j;
+                key[j] = i < P.fin_dcap ? __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+            // one value per workgroup (<= 512: eight independent loads per lane — a dependent loop over the W per-wave values
+            // costs a memory round trip per iteration, 61 of them at W = 3912)
+            u64 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = lane + 64 * j;
+                v[j] = b < (int)gridDim.x ? __hip_atomic_load(&P.fin_mm[(size_t)q * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : (((u64)0xFF800000u << 32) | 0x7F800000u);      // (-inf, +inf)
+            }
+            over |= over_l != 0;
+            const int total = __builtin_amdgcn_readfirstlane(total_l);
+            if (total > P.fin_dcap) { over = true; continue; }
             const int kk = P.k;
             int64_t* oi = P.out_ids + (size_t)q * kk;
             float* os = P.out_scores + (size_t)q * kk;
             const long long idb = P.id_base;
-            tiny_select_stream(total, kk, stage, carry, lane,
-                               [&](int i) -> u64 { return i < total ? __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; },
-                               [&](int r, u64 kv) {
-                                   oi[r] = kv ? (int64_t)cmr_key_row(kv) + idb : -1;
-                                   os[r] = kv ? cmr_key_score(kv) : -__builtin_inff();
-                               });
-            if (P.out_min || P.out_max) {
-                // one value per workgroup (<= 512: eight independent loads per lane — a dependent loop over the W per-wave values
-                // costs a memory round trip per iteration, 61 of them at W = 3912)
-                float mn = __builtin_inff(), mx = -__builtin_inff();
-                u64 v[8];
+            // (system-scope stores: the caller's buffer may be mapped host memory that the host polls — a plain store is acknowledged
+            // before it is visible there, and the done word behind s_waitcnt vmcnt(0) overtook the results: measured)
+            auto emit = [&](int r, u64 kv) {
+                __hip_atomic_store(&oi[r], kv ? (int64_t)cmr_key_row(kv) + idb : (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&os[r], kv ? cmr_key_score(kv) : -__builtin_inff(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            };
+            if (total <= 1024) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int b = lane + 64 * j;
-                    v[j] = b < (int)gridDim.x ? __hip_atomic_load(&P.fin_mm[(size_t)q * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                              : (((u64)0xFF800000u << 32) | 0x7F800000u);      // (-inf, +inf)
-                }
+                for (int j = 0; j < 16; ++j) key[j] = lane + 64 * j < total ? key[j] : 0ull;
+                tiny_select(key, kk, stage, lane, emit);
+            } else {
+                tiny_select_stream(total, kk, stage, carry, lane,
+                                   [&](int i) -> u64 { return i < total ? __hip_atomic_load(&D[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull; }, emit);
+            }
+            if (P.out_min || P.out_max) {
+                float mn = __builtin_inff(), mx = -__builtin_inff();
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { mn = fminf(mn, __uint_as_float((unsigned)v[j])); mx = fmaxf(mx, __uint_as_float((unsigned)(v[j] >> 32))); }
 #pragma unroll
                 for (int off2 = 32; off2 > 0; off2 >>= 1) { mn = fminf(mn, __shfl_xor(mn, off2)); mx = fmaxf(mx, __shfl_xor(mx, off2)); }
-                if (lane == 0) { if (P.out_min) P.out_min[q] = mn; if (P.out_max) P.out_max[q] = mx; }
+                if (lane == 0) {
+                    if (P.out_min) __hip_atomic_store(&P.out_min[q], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (P.out_max) __hip_atomic_store(&P.out_max[q], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         }
+        if (nq_g <= wave) over = __hip_atomic_load(&P.fin[CMR_FIN_OVER], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;      // (a wave without a query still reports the word)
         if (over && lane == 0) fin_sh[1] = 2;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's results are written through (the caller's buffer may be mapped host memory) before the state says so
         __syncthreads();
 #ifdef CMR_FIN_DEBUG
         if (tid == 0) {
@@ -772,6 +798,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         if (tid == 0) {
             P.fin[CMR_FIN_STATE] = fin_sh[1] == 2 ? 2 : 1;
             P.fin[CMR_FIN_DONE] = 0; P.fin[CMR_FIN_READY] = 0; P.fin[CMR_FIN_WGS] = 0; P.fin[CMR_FIN_OVER] = 0; P.fin[CMR_FIN_CLAIM] = 0;
+            if (P.fin_done) __hip_atomic_store(P.fin_done, fin_sh[1] == 2 ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the launch's last access to the caller's buffer
         }
     }
 }
@@ -847,7 +874,7 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.slists = a.sample_lists; p.scnt = a.sample_cnt; p.sW = a.sample_W;
     p.qgroups = a.qgroups > 1 ? a.qgroups : 1;
     p.fin_mm = a.fin_mm;
-    p.fin = a.fin; p.fin_pmax = a.fin_pmax; p.fin_tau = a.fin_tau; p.fin_dense = a.fin_dense; p.fin_wgs = a.fin_wgs; p.fin_mul = a.fin_mul; p.fin_dcap = a.fin_dcap; p.fin_spin = a.fin_spin;
+    p.fin = a.fin; p.fin_pmax = a.fin_pmax; p.fin_tau = a.fin_tau; p.fin_dense = a.fin_dense; p.fin_wgs = a.fin_wgs; p.fin_mul = a.fin_mul; p.fin_dcap = a.fin_dcap; p.fin_spin = a.fin_spin; p.fin_done = a.fin_done;
     p.out_ids = a.out_ids; p.out_scores = a.out_scores; p.out_min = a.out_min; p.out_max = a.out_max; p.id_base = a.id_base;
     return p;
 }

@@ -159,7 +159,7 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
  * paths), zero_copy, sample_single, sample_single_max, sample_tau_in_scan, sample_div, sample_maxmul, scan_fin (0: small synchronous
  * batches run the sampling / scan / merge chain instead of the scan with the finishing stage) / scan_fin_queries (<= 16) /
- * scan_fin_dense / scan_fin_spin, wide_mode (1: register-resident wide kernel | 2: query-split grid of the narrow kernel),
+ * scan_fin_dense / scan_fin_spin, sync_poll, wide_mode (1: register-resident wide kernel | 2: query-split grid of the narrow kernel),
  * stream_nt, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
  * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0: never | 1 | 2: every scan; default: scans shorter than ~1 ms) and
  * pipe_dual_scan (0 | 1; default: scans shorter than ~1 ms) — the pipelined search's streams with explicit CU masks (scans

@@ -175,3 +175,51 @@ def test_finishing_stage_keeps_the_key_a_compaction_made_the_threshold():
             assert _same(fin.search(Q[:1], k), one)
     assert fin.search(Q[:1], 1)[0][0, 0] == 399_990
     fin.close(); chain.close()
+
+
+@pytest.mark.parametrize("n,d", [(6, 64), (900, 128), (40_000, 64), (400_000, 64)])
+def test_polled_done_word_returns_what_the_stream_wait_returns(n, d):
+    """The synchronous host API polls a word in its mapped result buffer that the search's last kernel sets behind its results
+    (single-launch search and scan with the finishing stage; option sync_poll, default on) instead of waiting for the stream: call after call
+    on one workspace, batch sizes — hence buffer layouts — changing in between, must return what the stream wait returns (a done word that
+    overtook the results would hand back the previous call's bytes), a NaN query must still be reported, and the call after it must be clean."""
+    from comorag_amd._lib import CmrError, CMR_ERR_NONFINITE
+    X, Q = _mk(n, d, 16, seed=n % 89)
+    poll = _index("bf16", X, {"sync_poll": 1})
+    wait = _index("bf16", X, {"sync_poll": 0})
+    k = min(20, n)
+    rng = np.random.default_rng(5)
+    for rep in range(120):
+        m = int(rng.integers(1, 17))
+        q = Q[rng.permutation(16)[:m]] * np.float32(1.0 + 0.01 * rep)
+        assert _same(poll.search(q, k), wait.search(q, k)), (rep, m)
+        if rep % 40 == 7:
+            bad = q.copy(); bad[m // 2, 3] = np.nan
+            with pytest.raises(CmrError) as ei:
+                poll.search(bad, k)
+            assert ei.value.code == CMR_ERR_NONFINITE
+    for i in (poll, wait):
+        i.close()
+
+
+def test_polled_done_word_from_sixteen_threads_and_on_overflow():
+    import threading
+    X, Q = _mk(300_000, 64, 16, seed=3)
+    poll = _index("bf16", X, {"sync_poll": 1})
+    ref = [_index("bf16", X, {"sync_poll": 0, "scan_fin": 0}).search(Q[i:i + 1 + i % 4], 20) for i in range(12)]
+    errs = []
+    def work(t):
+        try:
+            for rep in range(25):
+                i = (t + rep) % 12
+                if not _same(poll.search(Q[i:i + 1 + i % 4], 20), ref[i]): errs.append((t, rep, i))
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs[:4]
+    # state 2 (every dense list overflows): the merge launch is issued by the polling host, only then
+    tight = _index("bf16", X, {"sync_poll": 1, "scan_fin_dense": 8})
+    for i in range(12):
+        assert _same(tight.search(Q[i:i + 1 + i % 4], 20), ref[i])
+    poll.close(); tight.close()

@@ -329,7 +329,7 @@ def f1_selfjoin(torch, device, entities=200_000, dim=768, thr=0.8, batch=1024, c
         # synchronisation, one download.  Best of three (round 5 timed the one-stream entry point here: 86-108 ms at bf16).
         ids_t = torch.empty((entities, 128), dtype=torch.int64, device=device); sc_t = torch.empty((entities, 128), dtype=torch.float32, device=device)
         qblock = 1000
-        t_join, t_one = None, None
+        t_join, t_one, t_down = None, None, None
         for rep in range(3):
             torch.cuda.synchronize(device)
             t0 = time.perf_counter(); done = None
@@ -338,9 +338,14 @@ def f1_selfjoin(torch, device, entities=200_000, dim=768, thr=0.8, batch=1024, c
                 done = idx.search_min_score_pipelined(x[b0:b1], 128, thr, ids_t[b0:b1], sc_t[b0:b1])
             idx.sync(done)
             torch.cuda.synchronize(device)
-            ids_h = ids_t.cpu().numpy()
             dt = time.perf_counter() - t0
             t_join = dt if t_join is None else min(t_join, dt)
+            # the [entities, 128] int64 ids to the host (205 MB through torch's pageable copy: what retrieve_knn does next), timed apart:
+            # the join is the device's work, the download is the link's
+            t1 = time.perf_counter()
+            ids_h = ids_t.cpu().numpy()
+            dl = time.perf_counter() - t1
+            t_down = dl if t_down is None else min(t_down, dl)
         passes = sum((min(b0 + qblock, entities) - b0 + 255) // 256 for b0 in range(0, entities, qblock))
         # the one-stream entry point on the same blocks (no overlap between a block's packing, scan and merge), for the fixed cost of a pass
         torch.cuda.synchronize(device)
@@ -360,7 +365,7 @@ def f1_selfjoin(torch, device, entities=200_000, dim=768, thr=0.8, batch=1024, c
         same = same and bool(np.array_equal(ids_h[:batch], a[0])) and bool(np.array_equal(ids_h, one_ids))
         ideal_us = 2.0 * 256 * entities * dim / (peak * 1e12) * 1e6 if dtype == "bf16" else None
         out[dtype] = {"threshold_search_whole_join_s": t_join, "route": f"throughput mode, blocks of {qblock} queries (retrieve_knn's), best of 3",
-                      "passes_of_up_to_256_queries": passes, "us_per_pass": t_join / passes * 1e6, "one_stream_whole_join_s": t_one, "one_stream_us_per_pass": t_one / passes * 1e6,
+                      "ids_download_s": t_down, "passes_of_up_to_256_queries": passes, "us_per_pass": t_join / passes * 1e6, "one_stream_whole_join_s": t_one, "one_stream_us_per_pass": t_one / passes * 1e6,
                       "us_per_pass_at_the_dtype_peak": ideal_us,
                       "threshold_search_host_blocks_s": t_thr * scale, "materialise_select_k2047_s": t_mat * scale,
                       "speedup": t_mat * scale / t_join,
