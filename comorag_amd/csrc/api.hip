@@ -197,6 +197,7 @@ struct cmr_index {
                              // instead of the scan with the finishing stage (thresholds and final selection inside the scan launch)
     int fin_dense = 16384;   // scan_fin_dense: keys per query of the finishing stage's dense candidate lists (~k x panels / 1024 beat a threshold taken
                              // from 1024 first panels: 600 at 1 M rows, 6 K at 10 M; a list that overflows hands the selection to the merge launch)
+    int fin_suppliers = 0;   // scan_fin_suppliers: workgroups whose first panels make the threshold sample (0: 64, 128 from 4 M rows up; <= 128)
     int fin_spin = 0;        // scan_fin_spin: rounds of ~1.5 us the workgroups that do not supply thresholds wait for them before they scan without (0: they look once)
     int fin_max_q = 8;       // scan_fin_queries: largest batch the finishing stage takes (<= 16).  Measured at 768-d bf16, per call, stage / chain:
                              // 1 M rows — 1 / 2 / 4 / 8 / 16 queries 287 / 292 / 297 / 322 / 392 us against 300 / 313 / 333 / 336 / 372;
@@ -242,6 +243,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "scan_fin") idx->scan_fin = (int)v;
     else if (n == "sync_poll") idx->sync_poll = (int)v;
     else if (n == "scan_fin_dense") idx->fin_dense = (int)std::max<long long>(1, std::min<long long>(v, 1 << 16));
+    else if (n == "scan_fin_suppliers") idx->fin_suppliers = (int)std::max<long long>(0, std::min<long long>(v, CMR_FIN_SLOTS / CMR_SCAN_WAVES));
     else if (n == "scan_fin_spin") idx->fin_spin = (int)std::max<long long>(0, std::min<long long>(v, 1000));
     else if (n == "scan_fin_queries") idx->fin_max_q = (int)std::max<long long>(1, std::min<long long>(v, CMR_FIN_MAX_QUERIES));
     else if (n == "sample_div") idx->sample_div = (int)std::max<long long>(2, v);
@@ -264,7 +266,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 // development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
-                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "sync_poll", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "sync_poll", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "scan_fin_suppliers", "sample_div", "sample_maxmul", "pipe_reserve_cus",
                                   "pipe_slots", "wide_waves", "wide_mode", "stream_nt", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
@@ -651,7 +653,10 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
         a.fin_mm = (u64*)ws->fin_mm.p;
         HIP_TRY(ws->fin_dense.ensure((size_t)32 * kFinDenseCap * 8));
         a.fin = (int*)ws->fin_ctl.p; a.fin_pmax = (u64*)ws->fin_pmax.p; a.fin_tau = (u64*)ws->fin_tau.p; a.fin_dense = (u64*)ws->fin_dense.p;
-        a.fin_wgs = std::min(CMR_FIN_SLOTS / CMR_SCAN_WAVES, g.grid);
+        // the first workgroups through their first panels supply the thresholds: 64 of them (512 maxima; the 64th of 256 is through at a
+        // third of the time the slowest of 128 takes), 128 from 4 M rows up (a looser threshold lets k x panels / maxima keys per query through)
+        a.fin_first = std::min(g.grid, idx->n_cu);      // (181 registers: one workgroup per CU)
+        a.fin_wgs = std::min(std::min(idx->fin_suppliers > 0 ? idx->fin_suppliers : (npanels >= 131072 ? 128 : 64), CMR_FIN_SLOTS / CMR_SCAN_WAVES), a.fin_first);
         // the golden-ratio multiple of the grid, moved to the next value coprime with it: the first fin_wgs workgroups' ranges spread evenly
         a.fin_mul = 1;
         for (int m = std::max(1, (int)(g.grid * 0.6180339887)); m < g.grid; ++m)

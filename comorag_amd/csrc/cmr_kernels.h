@@ -62,7 +62,8 @@ struct CmrScanArgs {
     u64* fin_tau;
     u64* fin_dense;
     u64* fin_mm;          // [32][grid] scratch
-    int fin_wgs;          // workgroups (the first dispatched) whose waves' first panels supply the thresholds: 8 x fin_wgs <= CMR_FIN_SLOTS maxima
+    int fin_wgs;          // workgroups (the first to be through their first panels) whose waves' first panels supply the thresholds: 8 x fin_wgs <= CMR_FIN_SLOTS maxima
+    int fin_first;        // workgroups of the first round (resident from the start: they cannot find thresholds when they begin); >= fin_wgs
     int fin_mul;          // workgroup b scans the panel ranges of virtual workgroup (b x fin_mul) mod grid (coprime with the grid; 1 = identity)
     int fin_dcap;
     int fin_spin;         // rounds (~1.5 us each) the other workgroups give the suppliers before they start without thresholds
@@ -83,11 +84,12 @@ struct CmrScanArgs {
 #define CMR_FIN_STATE 96      // result state: 1 = the scan wrote the final results itself, 2 = a list overflowed (the merge launch decides)
 #define CMR_FIN_OVER 128      // some workgroup's staging area overflowed
 #define CMR_FIN_DBG 136
+#define CMR_FIN_PUB 160       // supplying workgroups whose maxima are written through
 #define CMR_FIN_CLAIM 192     // queries whose threshold somebody has taken on
 #define CMR_FIN_MAX_QUERIES 16
 #define CMR_FIN_DCNT(q) (224 + 32 * (q))     // dense list lengths
 #define CMR_FIN_CTL (224 + 32 * 32)
-#define CMR_FIN_LDS 2048      // bytes of LDS the finishing stage adds to the geometry's (the waves' min / max)
+#define CMR_FIN_LDS 4096      // bytes of LDS the finishing stage adds to the geometry's (the waves' min / max and first-panel maxima)
 #define CMR_FIN_SLOTS 1024    // first-panel maxima the thresholds are taken from (one selection chunk of a wave)
 
 hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s);

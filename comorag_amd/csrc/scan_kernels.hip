@@ -118,7 +118,7 @@ struct ScanP {
     u64* fin_tau;          // [32] published thresholds
     u64* fin_dense;        // [32][fin_dcap] the candidates that beat their wave's final threshold
     u64* fin_mm;           // [32][grid] (min, max) per workgroup
-    int fin_wgs, fin_mul, fin_dcap, fin_spin;
+    int fin_wgs, fin_mul, fin_dcap, fin_spin, fin_first;
     int64_t* out_ids;
     float* out_scores;
     float* out_min;
@@ -223,7 +223,19 @@ __device__ __forceinline__ void fin_threshold(const u64* pmax, int ns, int k, u6
     });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) atomicOr(ready, 1 << q);
+#ifdef CMR_FIN_DEBUG
+    if (lane == 0) { atomicMin((unsigned*)(ready - CMR_FIN_READY + CMR_FIN_DBG + 2 + 3), (unsigned)wall_clock64()); atomicMax((unsigned*)(ready - CMR_FIN_READY + CMR_FIN_DBG + 2 + 4), (unsigned)wall_clock64()); }      // first / last threshold published
+#endif
 }
+
+// development builds (-DCMR_FIN_DEBUG): a timeline of the finishing stage in 10 ns ticks of the constant clock, slots behind CMR_FIN_DBG + 2
+#ifdef CMR_FIN_DEBUG
+#define CMR_FIN_STAMP_MIN(P, slot) atomicMin((unsigned*)&(P).fin[CMR_FIN_DBG + 2 + (slot)], (unsigned)wall_clock64())
+#define CMR_FIN_STAMP_MAX(P, slot) atomicMax((unsigned*)&(P).fin[CMR_FIN_DBG + 2 + (slot)], (unsigned)wall_clock64())
+#else
+#define CMR_FIN_STAMP_MIN(P, slot) ((void)0)
+#define CMR_FIN_STAMP_MAX(P, slot) ((void)0)
+#endif
 
 template <int DT, int NQT, int CAP, int R, int MODE, int ASMRING, int POL = 1>
 __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     // FIN only (the launcher adds CMR_FIN_LDS bytes): the waves' min / max per query, reduced per workgroup at the end
     float2* fin_mmw = reinterpret_cast<float2*>(stage_all + CMR_SCAN_WAVES * (CAP + 2) + 2);      // [waves][32]
     int* fin_sh = reinterpret_cast<int*>(stage_all + CMR_SCAN_WAVES * (CAP + 2));     // FIN: [0] the workgroup's ticket, [1] a staging area overflowed, [2] waves past their first panel
+    u64* fin_pm = reinterpret_cast<u64*>(fin_mmw + CMR_SCAN_WAVES * 32);             // FIN: [waves][32] per-query maxima of the waves' first panels
     // (dynamic LDS on purpose: the function's dynamic limit is the whole 160 KiB, a static variable on top of it fails the launch)
 
     // Query-split grid (batches of more than NQ queries in ONE corpus pass): the grid is qgroups x a virtual grid; the
@@ -277,6 +290,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     if (TOPK)
         for (int i = tid; i < CMR_SCAN_WAVES * NQ; i += CMR_SCAN_THREADS) cnt_all[i] = 0;
     if (FIN && tid == 0) { fin_sh[1] = 0; fin_sh[2] = 0; }
+    if constexpr (FIN) { if (tid == 0) { CMR_FIN_STAMP_MIN(P, 0); CMR_FIN_STAMP_MAX(P, 1); } }      // first / last workgroup start
     __syncthreads();
 
     const int W = vgrid * CMR_SCAN_WAVES;
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         // for that many rounds — a BOUNDED wait on workgroups that were dispatched earlier and wait for nobody, so it cannot
         // deadlock — but the head start does not pay: half the CUs idle while the suppliers' first panels stream at half the
         // rate (2 M rows, one query: scan 546 us with 40 rounds, 518 with none).
-        if ((int)blockIdx.x >= P.fin_wgs) {
+        if ((int)blockIdx.x >= P.fin_first) {
             if (wave == 0) {
                 int rdy = 0;
                 for (int spin = 0;; ++spin) {
@@ -536,32 +550,49 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                     int lane_o = lane;
                     asm volatile("" : "+v"(lane_o));
                     if (fin_phase == 0) {
-                        if ((int)blockIdx.x < P.fin_wgs) {
-                            u64 best = 0ull;
+                        // the per-query maxima of this wave's first panel go to LDS; the workgroup's last wave takes a ticket, and the first
+                        // fin_wgs workgroups to get one — the FASTEST, whichever they are: the slowest of a fixed set of 128 was through its
+                        // first panels at 58-95 us of a 270 us scan, the 64th of all at 31-36 (development build's stamps) — copy their eight
+                        // maxima per query to the ticket's slots
+                        u64 best = 0ull;
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const long long row = row0 + cmr_acc_row(r, lane_o);
-                                const float v = acc[0][r];
-                                const u64 key = cmr_make_key(v, (unsigned)row);
-                                if (row < P.nrows && v == v && key > best) best = key;
-                            }
-                            const u64 other = __shfl_xor(best, 32);
-                            best = other > best ? other : best;
-                            const int ns = P.fin_wgs * CMR_SCAN_WAVES;
-                            if (lane_o < nq_g)
-                                __hip_atomic_store(&P.fin_pmax[(size_t)lane_o * ns + (int)blockIdx.x * CMR_SCAN_WAVES + wave], best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // written through before this wave is counted
-                            int o = 0;
-                            if (lane_o == 0) o = atomicAdd(&fin_sh[2], 1);
-                            o = __builtin_amdgcn_readfirstlane(o);
-                            if (o == CMR_SCAN_WAVES - 1) {                            // the workgroup's last wave: one device atomic per workgroup
-                                int dn = 0;
-                                if (lane_o == 0) dn = atomicAdd(&P.fin[CMR_FIN_DONE], 1);
-                                dn = __builtin_amdgcn_readfirstlane(dn);
-                                if (dn == P.fin_wgs - 1) {
-                                    // every maximum is published: bit 31 says so, and the thresholds are taken query by query by
+                        for (int r = 0; r < 16; ++r) {
+                            const long long row = row0 + cmr_acc_row(r, lane_o);
+                            const float v = acc[0][r];
+                            const u64 key = cmr_make_key(v, (unsigned)row);
+                            if (row < P.nrows && v == v && key > best) best = key;
+                        }
+                        const u64 other = __shfl_xor(best, 32);
+                        best = other > best ? other : best;
+                        if (lane_o < 32) fin_pm[wave * 32 + lane_o] = lane_o < nq_g ? best : 0ull;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane_o == 0) { CMR_FIN_STAMP_MIN(P, 11); }      // the first first panel of a wave is through
+                        int o = 0;
+                        if (lane_o == 0) o = atomicAdd(&fin_sh[2], 1);
+                        o = __builtin_amdgcn_readfirstlane(o);
+                        if (o == CMR_SCAN_WAVES - 1) {                            // the workgroup's last wave: one device atomic per workgroup
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            int dn = 0;
+                            if (lane_o == 0) dn = atomicAdd(&P.fin[CMR_FIN_DONE], 1);
+                            dn = __builtin_amdgcn_readfirstlane(dn);
+#ifdef CMR_FIN_DEBUG
+                            if (lane_o == 0) { const int sl = dn == 0 ? 12 : dn == 15 ? 13 : dn == 31 ? 14 : dn == 63 ? 15 : dn == 95 ? 16 : -1; if (sl > 0) P.fin[CMR_FIN_DBG + 2 + sl] = (int)(unsigned)wall_clock64(); }
+#endif
+                            if (dn < P.fin_wgs) {
+                                const int ns = P.fin_wgs * CMR_SCAN_WAVES;
+                                if (lane_o < nq_g) {
+#pragma unroll
+                                    for (int w2 = 0; w2 < CMR_SCAN_WAVES; ++w2)
+                                        __hip_atomic_store(&P.fin_pmax[(size_t)lane_o * ns + dn * CMR_SCAN_WAVES + w2], fin_pm[w2 * 32 + lane_o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // written through before this workgroup is counted
+                                int pb = 0;
+                                if (lane_o == 0) pb = atomicAdd(&P.fin[CMR_FIN_PUB], 1);
+                                pb = __builtin_amdgcn_readfirstlane(pb);
+                                if (pb == P.fin_wgs - 1) {
+                                    // every slot is filled: bit 31 says so, and the thresholds are taken query by query by
                                     // whoever claims one — this wave, and every wave that comes past a panel end meanwhile
-                                    if (lane_o == 0) atomicOr(&P.fin[CMR_FIN_READY], (int)0x80000000u);
+                                    if (lane_o == 0) { atomicOr(&P.fin[CMR_FIN_READY], (int)0x80000000u); CMR_FIN_STAMP_MAX(P, 2); }      // every slot of first-panel maxima filled
                                     // (a counted loop, every lane in the atomic: whatever the compiler makes of it, it ends)
                                     for (int it = 0; it < nq_g; ++it) {
                                         int cq = __hip_atomic_fetch_add(&P.fin[CMR_FIN_CLAIM], lane_o == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -573,7 +604,9 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                             }
                         }
                         fin_phase = 1;
-                    } else if (fin_phase == 1) {
+                    }
+                    // (a wave whose first panel ends after the thresholds were published adopts them here and now, not a panel later)
+                    if (fin_phase == 1) {
                         const int rd = __hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const int full = (int)((1u << nq_g) - 1u);
                         if ((rd & full) == full) {
@@ -582,7 +615,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                             if (q < nq_g && gt > tau_key[0]) { tau_key[0] = gt; tau_f[0] = cmr_key_score(gt); }
                             fin_phase = 2;
 #ifdef CMR_FIN_DEBUG
-                            if (lane_o == 0) { atomicAdd(&P.fin[CMR_FIN_DBG], 1); atomicAdd(&P.fin[CMR_FIN_DBG + 1], p - p0); }
+                            if (lane_o == 0) { atomicAdd(&P.fin[CMR_FIN_DBG], 1); atomicAdd(&P.fin[CMR_FIN_DBG + 1], p - p0); CMR_FIN_STAMP_MIN(P, 5); CMR_FIN_STAMP_MAX(P, 6); }      // first / last adoption
 #endif
                         } else if (rd < 0) {                      // published, thresholds incomplete: take one
                             int cq = __hip_atomic_fetch_add(&P.fin[CMR_FIN_CLAIM], lane_o == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -639,6 +672,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         }
     }
     if constexpr (FIN) {
+        if (lane == 0) { CMR_FIN_STAMP_MIN(P, 7); CMR_FIN_STAMP_MAX(P, 8); }      // first / last wave out of its scan loop
         // Finishing stage, part 2 — the final selection without a merge launch.  Every wave stages the keys of its lists that beat
         // its FINAL threshold (any threshold a wave holds is a valid lower bound of the global k-th best: nothing that can win is
         // dropped) in its LDS scratch; the workgroup appends them to one dense list per query with ONE device atomic per query,
@@ -722,6 +756,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             if (fin_sh[1]) __hip_atomic_store(&P.fin[CMR_FIN_OVER], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fin_sh[0] = atomicAdd(&P.fin[CMR_FIN_WGS], 1);
+            CMR_FIN_STAMP_MIN(P, 9); CMR_FIN_STAMP_MAX(P, 10);      // first / last ticket
         }
         __syncthreads();
         if (fin_sh[0] != (int)gridDim.x - 1) return;
@@ -791,13 +826,24 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             printf("FIN grid %d W %d wgs %d mul %d: done %d ready %d | adoptions %d, panels before adoption (sum) %d | dense[0] %d tau0 %f over %d\n",
                    (int)gridDim.x, W, P.fin_wgs, P.fin_mul, P.fin[CMR_FIN_DONE], P.fin[CMR_FIN_READY], P.fin[CMR_FIN_DBG], P.fin[CMR_FIN_DBG + 1],
                    P.fin[CMR_FIN_DCNT(0)], cmr_key_score(P.fin_tau[0]), fin_sh[1]);
+            {
+                const unsigned* T = (const unsigned*)&P.fin[CMR_FIN_DBG + 2];
+                const unsigned t0 = T[0], te = (unsigned)wall_clock64();
+                auto us = [&](unsigned t) { return (t - t0) * 0.01f; };
+                printf("FIN us since the first workgroup started: last start %.1f | maxima published %.1f | thresholds %.1f .. %.1f | adoptions %.1f .. %.1f | "
+                       "waves out of the scan %.1f .. %.1f | tickets %.1f .. %.1f | selection written %.1f\n",
+                       us(T[1]), us(T[2]), us(T[3]), us(T[4]), us(T[5]), us(T[6]), us(T[7]), us(T[8]), us(T[9]), us(T[10]), us(te));
+                printf("FIN    first supplying wave through its first panel %.1f | supplying workgroups complete: 1st %.1f, 16th %.1f, 32nd %.1f, 64th %.1f, 96th %.1f, all %d %.1f\n",
+                       us(T[11]), us(T[12]), us(T[13]), us(T[14]), us(T[15]), us(T[16]), P.fin_wgs, us(T[2]));
+                for (int i = 0; i < 17; ++i) P.fin[CMR_FIN_DBG + 2 + i] = (i == 0 || i == 3 || i == 5 || i == 7 || i == 9 || i == 11) ? -1 : 0;
+            }
             P.fin[CMR_FIN_DBG] = 0; P.fin[CMR_FIN_DBG + 1] = 0;
         }
 #endif
         if (tid < 32) P.fin[CMR_FIN_DCNT(tid)] = 0;
         if (tid == 0) {
             P.fin[CMR_FIN_STATE] = fin_sh[1] == 2 ? 2 : 1;
-            P.fin[CMR_FIN_DONE] = 0; P.fin[CMR_FIN_READY] = 0; P.fin[CMR_FIN_WGS] = 0; P.fin[CMR_FIN_OVER] = 0; P.fin[CMR_FIN_CLAIM] = 0;
+            P.fin[CMR_FIN_DONE] = 0; P.fin[CMR_FIN_READY] = 0; P.fin[CMR_FIN_WGS] = 0; P.fin[CMR_FIN_OVER] = 0; P.fin[CMR_FIN_CLAIM] = 0; P.fin[CMR_FIN_PUB] = 0;
             if (P.fin_done) __hip_atomic_store(P.fin_done, fin_sh[1] == 2 ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the launch's last access to the caller's buffer
         }
     }
@@ -874,7 +920,7 @@ static ScanP to_p(const CmrScanGeom& g, const CmrScanArgs& a) {
     p.slists = a.sample_lists; p.scnt = a.sample_cnt; p.sW = a.sample_W;
     p.qgroups = a.qgroups > 1 ? a.qgroups : 1;
     p.fin_mm = a.fin_mm;
-    p.fin = a.fin; p.fin_pmax = a.fin_pmax; p.fin_tau = a.fin_tau; p.fin_dense = a.fin_dense; p.fin_wgs = a.fin_wgs; p.fin_mul = a.fin_mul; p.fin_dcap = a.fin_dcap; p.fin_spin = a.fin_spin; p.fin_done = a.fin_done;
+    p.fin = a.fin; p.fin_pmax = a.fin_pmax; p.fin_tau = a.fin_tau; p.fin_dense = a.fin_dense; p.fin_wgs = a.fin_wgs; p.fin_mul = a.fin_mul; p.fin_dcap = a.fin_dcap; p.fin_spin = a.fin_spin; p.fin_done = a.fin_done; p.fin_first = a.fin_first;
     p.out_ids = a.out_ids; p.out_scores = a.out_scores; p.out_min = a.out_min; p.out_max = a.out_max; p.id_base = a.id_base;
     return p;
 }
@@ -1682,7 +1728,7 @@ hipError_t cmr_launch_scan_topk(const CmrScanGeom& g, const CmrScanArgs& a, hipS
 // top-k scan with thresholds and final selection inside the launch (MODE_FIN: one query tile, <= fin_ns <= 1024 first-panel slots)
 hipError_t cmr_launch_scan_fin(const CmrScanGeom& g, const CmrScanArgs& a, hipStream_t s) {
     if (g.nqt != 1 || a.qgroups > 1 || !a.fin || !a.fin_pmax || !a.fin_tau || !a.fin_dense || a.fin_wgs < 1 || a.fin_wgs * CMR_SCAN_WAVES > CMR_FIN_SLOTS ||
-        a.fin_wgs > g.grid || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || !tiny_select_stream_ok((long long)a.fin_dcap + 1025, a.k) || a.nq > CMR_FIN_MAX_QUERIES || !a.out_ids || !a.out_scores || a.sample_waves > 0)
+        a.fin_wgs > g.grid || a.fin_first < a.fin_wgs || a.fin_mul < 1 || a.fin_dcap < 1 || !a.fin_mm || g.grid > 512 || !tiny_select_stream_ok((long long)a.fin_dcap + 1025, a.k) || a.nq > CMR_FIN_MAX_QUERIES || !a.out_ids || !a.out_scores || a.sample_waves > 0)
         return hipErrorInvalidValue;
     const ScanP p = to_p(g, a);
     CmrScanGeom gf = g;
