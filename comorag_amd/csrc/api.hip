@@ -197,6 +197,7 @@ struct cmr_index {
                              // instead of the scan with the finishing stage (thresholds and final selection inside the scan launch)
     int fin_dense = 16384;   // scan_fin_dense: keys per query of the finishing stage's dense candidate lists (~k x panels / 1024 beat a threshold taken
                              // from 1024 first panels: 600 at 1 M rows, 6 K at 10 M; a list that overflows hands the selection to the merge launch)
+    int fin_cap = 0;         // scan_fin_cap: keys per (wave, query) list of the scan with the finishing stage (128 | 256; 0: the geometry's, by k).  256 measured: 1 M rows, 8 queries 304-309 us against 314-317, everything else level (2 M rows 548-552 against 537-548)
     int fin_suppliers = 0;   // scan_fin_suppliers: workgroups whose first panels make the threshold sample (0: 64, 128 from 4 M rows up; <= 128)
     int fin_spin = 0;        // scan_fin_spin: rounds of ~1.5 us the workgroups that do not supply thresholds wait for them before they scan without (0: they look once)
     int fin_max_q = 8;       // scan_fin_queries: largest batch the finishing stage takes (<= 16).  Measured at 768-d bf16, per call, stage / chain:
@@ -243,6 +244,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
     else if (n == "scan_fin") idx->scan_fin = (int)v;
     else if (n == "sync_poll") idx->sync_poll = (int)v;
     else if (n == "scan_fin_dense") idx->fin_dense = (int)std::max<long long>(1, std::min<long long>(v, 1 << 16));
+    else if (n == "scan_fin_cap") { if (v != 0 && v != 128 && v != 256) return fail(CMR_ERR_INVALID, "scan_fin_cap must be 0, 128 or 256"); idx->fin_cap = (int)v; }
     else if (n == "scan_fin_suppliers") idx->fin_suppliers = (int)std::max<long long>(0, std::min<long long>(v, CMR_FIN_SLOTS / CMR_SCAN_WAVES));
     else if (n == "scan_fin_spin") idx->fin_spin = (int)std::max<long long>(0, std::min<long long>(v, 1000));
     else if (n == "scan_fin_queries") idx->fin_max_q = (int)std::max<long long>(1, std::min<long long>(v, CMR_FIN_MAX_QUERIES));
@@ -266,7 +268,7 @@ int set_option(cmr_index* idx, const char* name, long long v) {
 // development builds (-DCMR_DEV_KNOBS, tools/): the same options from the environment, CMR_<OPTION NAME IN CAPITALS>
 void options_from_env(cmr_index* idx) {
     static const char* names[] = {"scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small",
-                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "sync_poll", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "scan_fin_suppliers", "sample_div", "sample_maxmul", "pipe_reserve_cus",
+                                  "small_max_panels", "tiny_multi", "zero_copy", "sample_single", "sample_single_max", "sample_tau_in_scan", "scan_fin", "sync_poll", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "scan_fin_suppliers", "scan_fin_cap", "sample_div", "sample_maxmul", "pipe_reserve_cus",
                                   "pipe_slots", "wide_waves", "wide_mode", "stream_nt", "pipe_dual_scan", "pipe_cu_mask", "wide_abl"};
     for (const char* nm : names) {
         std::string env = "CMR_";
@@ -475,6 +477,13 @@ int enqueue_pass(cmr_index* idx, Workspace* ws, hipStream_t sp, hipStream_t sm, 
     bool fin = idx->scan_fin && !idx->no_sample && !wide && G == 1 && !min_score && sp == sm && sm == sq && g.nqt == 1 && nqp <= idx->fin_max_q &&
                k <= 64 && npanels >= 4096 && npanels >= (long long)idx->n_cu * 2 * CMR_SCAN_WAVES;      // (every wave of the grid has a first panel)
     if (fin) {
+        // scan_fin_cap = 256: longer lists than k asks for — the panels a wave scans before the thresholds arrive go to its lists whole (32 keys
+        // per query and panel, two to three panels), and a 128-key list is then "nearly full" at the first real candidate (a compaction)
+        if ((idx->fin_cap == 256 || idx->fin_cap == 128) && idx->fin_cap > g.cap) {
+            CmrScanGeom g2 = g;
+            g2.cap = idx->fin_cap;
+            if (cmr_scan_geom(&g2) && g2.lds + CMR_FIN_LDS <= 160 * 1024) g = g2;      // (else: the geometry's own lists)
+        }
         const bool ok = cmr_ring_audit_ok(g.dtype, 1, g.cap, g.ring, 2);
         if (idx->force_asm == 1 && !ok) fin = false;       // the caller insists on the hand-counted ring: only audited variants
         if (g.lds + CMR_FIN_LDS > 160 * 1024 || g.grid > 512) fin = false;

@@ -6,7 +6,7 @@ import os
 
 OPTION_NAMES = ("scan_ring", "scan_asm_ring", "scan_grid", "scan_no_sample", "scan_no_wide", "scan_no_tiny", "scan_no_small", "small_max_panels",
                 "tiny_multi", "zero_copy", "sample_single", "sample_tau_in_scan", "sample_div", "sample_maxmul", "pipe_reserve_cus", "pipe_slots", "wide_waves",
-                "pipe_dual_scan", "pipe_cu_mask", "wide_abl", "wide_mode", "stream_nt", "sample_single_max", "scan_fin", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "sync_poll", "scan_fin_suppliers")
+                "pipe_dual_scan", "pipe_cu_mask", "wide_abl", "wide_mode", "stream_nt", "sample_single_max", "scan_fin", "scan_fin_queries", "scan_fin_dense", "scan_fin_spin", "sync_poll", "scan_fin_suppliers", "scan_fin_cap")
 
 
 def env_options() -> dict:
