@@ -332,6 +332,26 @@ int check_device(int device_id) {
     return CMR_OK;
 }
 
+// Synchronous host API, results in the workspace's pinned, device-mapped buffer: the search's last kernel stores a word (bytes 4..7 of the
+// buffer, zeroed by the caller before the launch) behind its results — both by system-scope stores, the device's writes arrive in order —
+// and the host polls it: seen ~5.5 us before hipStreamSynchronize returns (tools/probe/poll_probe.hip).  Bounded: a launch that never
+// reports (a fault) is left to the stream, whose error comes back.
+int wait_done_word(Workspace* ws, int* state = nullptr) {
+    volatile int* const w = (volatile int*)((char*)ws->h_pin + 4);
+    int st = *w;
+    if (!st) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 1; !(st = *w); ++spin) {
+            __builtin_ia32_pause();
+            if ((spin & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!st) { HIP_TRY(hipStreamSynchronize(ws->stream)); st = *w; }
+    if (state) *state = st;
+    return CMR_OK;
+}
+
 // the workspace's non-finite flag, allocated and zeroed on first use
 int arm_flag(Workspace* ws, hipStream_t s) {
     if (ws->flag_ptr) return CMR_OK;
@@ -1515,19 +1535,8 @@ int cmr_index_search_finish(CmrPending* P, int64_t* out_ids, float* out_scores, 
     if (rc) return rc;
     Workspace* ws = P->ws;
     if (P->poll) {
-        // the last kernel of the search stores this word behind its results (both in the pinned buffer: the device's writes arrive in
-        // order): seen ~5.5 us before hipStreamSynchronize returns.  Bounded: a launch that never reports (a fault) is left to the stream.
-        volatile int* const w = (volatile int*)((char*)ws->h_pin + 4);
-        int st = *w;
-        if (!st) {
-            const auto t0 = std::chrono::steady_clock::now();
-            for (unsigned spin = 1; !(st = *w); ++spin) {
-                __builtin_ia32_pause();
-                if ((spin & 4095u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        if (!st) { HIP_TRY(hipStreamSynchronize(ws->stream)); st = *w; }
+        int st = 0;
+        { int rc_ = wait_done_word(ws, &st); if (rc_) return rc_; }
         if (ws->lazy.due && st != 1) {      // a dense list or a staging area of the finishing stage overflowed: the merge works from the per-wave lists
             const Workspace::LazyMerge& L = ws->lazy;
             ws->lazy.due = false;
@@ -1643,9 +1652,14 @@ int32_t cmr_index_scores(cmr_index_t* idx, const float* q, int32_t nq, float* ou
                 q_in = (const float*)ws->d_q.p;
             }
             HIP_TRY(ws->d_out.ensure((size_t)nq * npanels * CMR_PANEL_ROWS * 4));
+            if (idx->sync_poll && !ws->arrive.p) {          // arrival counter: zeroed once, re-armed by the kernel
+                HIP_TRY(ws->arrive.ensure(sizeof(int)));
+                HIP_TRY(hipMemsetAsync(ws->arrive.p, 0, sizeof(int), s));
+            }
             HIP_TRY(cmr_launch_tiny_scores(idx->dtype, idx->corpus, q_in, nq, idx->dim, idx->dpad, idx->n, ws->d_out.p, (float*)(d + o_sc), idx->n,
-                                           (int*)d, s));
-            HIP_TRY(hipStreamSynchronize(s));
+                                           (int*)d, s, idx->sync_poll ? (int*)ws->arrive.p : nullptr, idx->sync_poll ? (int*)(d + 4) : nullptr));
+            if (idx->sync_poll) { int rc_ = wait_done_word(ws); if (rc_) return rc_; }      // the last workgroup's word behind everybody's rows (bytes 4..7, zeroed above)
+            else HIP_TRY(hipStreamSynchronize(s));
             int flagged = 0;
             memcpy(&flagged, h, sizeof(int));
             if (flagged) return fail(CMR_ERR_NONFINITE, "query contains NaN/Inf");

@@ -522,8 +522,25 @@ __global__ __launch_bounds__(512) void tiny_search_kernel(const v4u* __restrict_
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int row_lo = p_lo * CMR_PANEL_ROWS, row_hi = p_hi * CMR_PANEL_ROWS < nrows ? p_hi * CMR_PANEL_ROWS : nrows;
+        if (!done) {
+            for (int qi = 0; qi < nq; ++qi)
+                for (int row = row_lo + tid; row < row_hi; row += 512) out_full[(size_t)qi * ld_out + row] = scratch[(size_t)qi * ld + row];
+            return;
+        }
+        // a synchronous caller polls the done word of its mapped buffer: the rows leave by system-scope stores (visible to the host once
+        // acknowledged), every workgroup is counted behind its own, and the last one to arrive sets the word
         for (int qi = 0; qi < nq; ++qi)
-            for (int row = row_lo + tid; row < row_hi; row += 512) out_full[(size_t)qi * ld_out + row] = scratch[(size_t)qi * ld + row];
+            for (int row = row_lo + tid; row < row_hi; row += 512)
+                __hip_atomic_store(&out_full[(size_t)qi * ld_out + row], scratch[(size_t)qi * ld + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int t = nwg > 1 ? atomicAdd(arrive, 1) : 0;
+            if (t == nwg - 1) {
+                if (nwg > 1) *arrive = 0;                               // re-armed for the next launch
+                __hip_atomic_store(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         return;
     }
     u64* stage = tiny_stage[wave];
@@ -660,7 +677,7 @@ static hipError_t tiny_launch(int dtype, const void* corpus, const float* q, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDynLds); \
         if (e != hipSuccess) return e;                                                                                               \
         hipLaunchKernelGGL(tiny_search_kernel<DT>, dim3(g.nwg), dim3(512), lds, s, c, q, nq, dim, ks, (int)nrows, npanels, k, id_base, scores, out_ids, \
-                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm, out_full, ld_out, out_full ? nullptr : done); \
+                           out_scores, out_min, out_max, flag, stage_raw, arrive, g.ppw, cand, pmm, out_full, ld_out, (out_full && !arrive) ? nullptr : done); \
     }
     switch (dtype) {
         case CMR_DT_BF16: TS(CMR_DT_BF16) break;
@@ -681,8 +698,8 @@ hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q,
 
 // all raw scores [nq, ld_out] of a small corpus (nq <= 16) in one launch; scratch: nq * npanels * 32 floats
 hipError_t cmr_launch_tiny_scores(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, void* scratch,
-                                  float* out, long long ld_out, int* flag, hipStream_t s) {
-    return tiny_launch(dtype, corpus, q, nq, dim, dpad, nrows, 1, 0, scratch, nullptr, nullptr, nullptr, nullptr, flag, nullptr, 1 << 30, out, ld_out, s);
+                                  float* out, long long ld_out, int* flag, hipStream_t s, int* arrive, int* done) {
+    return tiny_launch(dtype, corpus, q, nq, dim, dpad, nrows, 1, 0, scratch, nullptr, nullptr, nullptr, nullptr, flag, arrive, 1 << 30, out, ld_out, s, arrive ? done : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

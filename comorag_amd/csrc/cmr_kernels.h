@@ -127,7 +127,7 @@ hipError_t cmr_launch_tiny_search(int dtype, const void* corpus, const float* q,
                                   void* scratch, int64_t* out_ids, float* out_scores, float* out_min, float* out_max, int* flag, int* arrive,
                                   int max_panels, hipStream_t s, int* done = nullptr);      // done: as CmrScanArgs::fin_done (set to 1 behind the results)
 hipError_t cmr_launch_tiny_scores(int dtype, const void* corpus, const float* q, int nq, int dim, int dpad, long long nrows, void* scratch,
-                                  float* out, long long ld_out, int* flag, hipStream_t s);
+                                  float* out, long long ld_out, int* flag, hipStream_t s, int* arrive = nullptr, int* done = nullptr);      // arrive (zeroed device int) + done: the last workgroup sets *done = 1 behind everybody's rows
 // per-row top-k (k <= 4096) of a materialised score matrix [nq, ld]
 hipError_t cmr_launch_topk_rows(const float* scores, long long ld, int n, int nq, int k, long long id_base,
                                 int64_t* out_ids, float* out_scores, float* out_min, float* out_max, hipStream_t s);

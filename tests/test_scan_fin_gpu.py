@@ -193,10 +193,15 @@ def test_polled_done_word_returns_what_the_stream_wait_returns(n, d):
         m = int(rng.integers(1, 17))
         q = Q[rng.permutation(16)[:m]] * np.float32(1.0 + 0.01 * rep)
         assert _same(poll.search(q, k), wait.search(q, k)), (rep, m)
+        if rep % 3 == 0:        # all N scores per query (single launch up to 192 K rows: every workgroup's rows, then the last one's word)
+            assert np.array_equal(poll.scores(q), wait.scores(q)), (rep, m)
         if rep % 40 == 7:
             bad = q.copy(); bad[m // 2, 3] = np.nan
             with pytest.raises(CmrError) as ei:
                 poll.search(bad, k)
+            assert ei.value.code == CMR_ERR_NONFINITE
+            with pytest.raises(CmrError) as ei:
+                poll.scores(bad)
             assert ei.value.code == CMR_ERR_NONFINITE
     for i in (poll, wait):
         i.close()
