@@ -129,7 +129,7 @@ struct Workspace {
 
 struct ProfEvent { hipEvent_t a, b; };
 
-constexpr size_t kMappedAppendMax = 64 * 1024;  // appends up to this many bytes of fp32 rows are read by the convert kernel from mapped host memory
+constexpr size_t kMappedAppendMax = 128 * 1024;  // appends up to this many bytes of fp32 rows are read by the convert kernel from mapped host memory (BASELINE config 4 appends 25 rows x 768 = 75 KiB per cycle)
 constexpr size_t kZeroCopyMax = 256 * 1024;   // synchronous host API: queries / results up to this size are mapped, not copied
 
 struct PipeSlot { Workspace ws; hipEvent_t pre_done = nullptr, scan_done = nullptr, main_done = nullptr; bool used = false; };

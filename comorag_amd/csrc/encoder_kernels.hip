@@ -65,6 +65,27 @@ template <int DT> __device__ __forceinline__ void enc_unpack2(unsigned u, float&
 #else
 #define ATT_VSTR 68           // V^T rows in LDS: 64 keys + 4 (136 B: ds_read_b64 of 32 consecutive d rows hit 32 different bank pairs)
 #endif
+// Round 6, measured with the kernel's own duration (rocprofv3 --kernel-trace, tools/attn_variants.sh; 32 x 512 x 12 heads bf16, full and ragged
+// mini-batches averaged, two runs on one box): round 5's kernel 41.6 / 40.9 us; + packed softmax arithmetic (ATT_PK) 39.5 / 40.3 — kept;
+// + unpadded XOR-swizzled K / V rows written through registers (ATT_SWZL: SQ_LDS_BANK_CONFLICT 37 K -> 0, LDS-array cycles -41 %) 41.1 / 41.4;
+// + the chunks by LDS-DMA instead of registers (ATT_DMA: VGPRs 120 -> 112, no ds_write) 42.0 / 41.6.  Neither the bank conflicts nor the
+// register staging is what bounds this kernel: the swizzle's address arithmetic costs a VALU-bound loop more than the conflicts did.
+#ifndef ATT_PK
+#define ATT_PK 1              // 1: the softmax's multiply-adds and sums two scores per instruction (v_pk_fma_f32 / v_pk_add_f32)
+#endif
+#ifndef ATT_DMA
+#define ATT_DMA 0             // 1 (needs ATT_VTR): K / V chunks go HBM / L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write),
+#endif                        //    rows unpadded (128 B) and XOR-swizzled by 16-byte segment so that both read patterns stay conflict-free; 0: through registers
+#ifndef ATT_SWZL
+#define ATT_SWZL 0            // 1 (needs ATT_VTR): K / V rows in LDS unpadded and XOR-swizzled by 16-byte segment (ATT_SWZ below) — no bank conflict on either read;
+#endif                        //    0: padded rows (ATT_KSTR / ATT_VSTR).  ATT_DMA implies it (a DMA instruction lands 1 KiB lane-linear: no padding possible)
+#if ATT_DMA && !ATT_SWZL
+#undef ATT_SWZL
+#define ATT_SWZL 1
+#endif
+#if ATT_SWZL && !ATT_VTR
+#error "the swizzled layout stages V row-major: it needs ATT_VTR"
+#endif
 typedef short att_v4s __attribute__((ext_vector_type(4)));
 #define ATT_NEG (-1.0e30f)
 #ifndef ATT_MIN_WG
@@ -85,8 +106,22 @@ template <int DT, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_kernel(const unsigned short* __restrict__ qkv, const int* __restrict__ lens, int L, int hidden,
                                                            int n_heads, int n_qblocks, int total, float sc /* log2(e) / sqrt(64) */,
                                                            unsigned short* __restrict__ out) {
+#if ATT_SWZL
+    // [key][64 d] unpadded (two rows per 256-byte bank row), 16-byte segment sg of row r at slot sg ^ f(r), f = ATT_SWZ: a DMA instruction lands
+    // 8 rows x 128 B lane-linear (the lane picks the SOURCE segment that belongs in its slot).  f permutes the bits of u = (r >> 1) & 7 —
+    // (u & 1) << 2 | u >> 1 — so that (MI355X_MICROARCH.md, LDS: 64 banks, lane groups per instruction)
+    //   * ds_read_b128 of QK^T: a 16-lane group {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} reads one segment of 16 rows; its eight even rows
+    //     have eight different u, its eight odd rows (the other half of the bank row) too: 16 different slots;
+    //   * ds_read_b64_tr_b16 of PV: a 32-lane group reads four segments of four consecutive rows; rows r and r + 2 share a half of the bank
+    //     row and differ in bit 2 of f: their segment sets {4 dt .. 4 dt + 3} ^ f are disjoint.
+    // (first version: f = r & 7 — SQ_LDS_BANK_CONFLICT twice the padded layout's, rows r and r + 2 of a transposing read on the same slots)
+#define ATT_SWZ(r) (((((r) >> 1) & 1) << 2) | ((((r) >> 1) & 7) >> 1))
+    __shared__ __attribute__((aligned(1024))) unsigned short k_lds[2][ATT_CHUNK * 64];
+    __shared__ __attribute__((aligned(1024))) unsigned short v_lds[2][ATT_CHUNK * 64];
+#else
     __shared__ __attribute__((aligned(16))) unsigned short k_lds[2][ATT_CHUNK * ATT_KSTR];
     __shared__ __attribute__((aligned(16))) unsigned short v_lds[2][64 * ATT_VSTR];      // ATT_VTR: [key][d], else [d][key]
+#endif
     // workgroup id -> work item.  Hardware deals workgroup ids round-robin over the 8 XCDs: the query blocks of one (sequence, head)
     // pair stay on ONE XCD, so the pair's K / V come out of that XCD's L2 after the first block; the PAIRS go round the XCDs, so every
     // XCD holds a share of every sequence.  (Round 4 kept a whole sequence — all its heads — on one XCD: in a mini-batch of mixed
@@ -127,6 +162,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
         if (qrow < L) qf[ks] = *reinterpret_cast<const v4u*>(qbase + (size_t)qrow * rs + ks * 16 + g * 8);
     }
 
+#if ATT_DMA
+    // chunk staging by LDS-DMA: wave w brings rows 8w + PROWS*h .. + 7 of K and of V (one instruction each: 64 lanes x 16 B = 8 rows), lane l the
+    // segment (l & 7) ^ f(row) of row l >> 3 into slot l & 7.  Rows beyond the sequence re-read its last row: finite values under p = 0
+    // (a lane switched off would leave whatever the buffer held, and 0 x Inf is NaN).  Inline asm (M0 = LDS destination): hipcc neither
+    // counts these loads nor knows that the LDS reads depend on them — the wait in front of the chunk's barrier is written out below.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);      // (M0 takes an SGPR)
+    const int dr = lane >> 3, dsg = (lane & 7) ^ ATT_SWZ(dr + 8 * (wave_u & 1));      // (a wave's rows start at a multiple of 8: bit 3 of the row = wave & 1)
+    const unsigned k_dst = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned short*)&k_lds[0][0]) + (unsigned)wave_u * 1024u;
+    const unsigned v_dst = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned short*)&v_lds[0][0]) + (unsigned)wave_u * 1024u;
+    auto dma_chunk = [&](int ch, int buf) {
+        const int k0 = ch * ATT_CHUNK;
+#pragma unroll
+        for (int h = 0; h < PASSES; ++h) {
+            int key = k0 + wave * 8 + PROWS * h + dr;
+            key = key < len ? key : len - 1;
+            const unsigned voff = ((unsigned)key * (unsigned)rs + (unsigned)dsg * 8u) * 2u;
+            const unsigned dk = k_dst + (unsigned)buf * (ATT_CHUNK * 128u) + (unsigned)h * (PROWS * 128u);
+            const unsigned dv = v_dst + (unsigned)buf * (ATT_CHUNK * 128u) + (unsigned)h * (PROWS * 128u);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(kbase), "s"(dk) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(vbase), "s"(dv) : "memory", "m0");
+        }
+    };
+#endif
     // chunk staging.  K: thread -> rows r and r + 32, 16-byte segment seg.  V: thread -> the key pair pi, d segment dseg.
     const int kr = tid >> 3, kseg = tid & 7;
     const int pi = wave * 8 + (lane & 7), dseg = lane >> 3;
@@ -145,11 +203,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
+#if ATT_SWZL
+        for (int h = 0; h < PASSES; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + PROWS * h) * 64 + ((kseg ^ ATT_SWZ(kr + PROWS * h)) * 8)]) = kreg[h];
+#pragma unroll
+        for (int h = 0; h < (ATT_ABL == 6 ? 0 : PASSES); ++h) *reinterpret_cast<v4u*>(&v_lds[buf][(kr + PROWS * h) * 64 + ((kseg ^ ATT_SWZ(kr + PROWS * h)) * 8)]) = vreg[h];
+#elif ATT_VTR
         for (int h = 0; h < PASSES; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + PROWS * h) * ATT_KSTR + kseg * 8]) = kreg[h];
-#if ATT_VTR
 #pragma unroll
         for (int h = 0; h < (ATT_ABL == 6 ? 0 : PASSES); ++h) *reinterpret_cast<v4u*>(&v_lds[buf][(kr + PROWS * h) * ATT_VSTR + kseg * 8]) = vreg[h];
 #else
+        for (int h = 0; h < PASSES; ++h) *reinterpret_cast<v4u*>(&k_lds[buf][(kr + PROWS * h) * ATT_KSTR + kseg * 8]) = kreg[h];
 #pragma unroll
         for (int w = 0; w < (ATT_ABL == 6 ? 0 : 4); ++w) {                  // element 2w and 2w + 1 of both keys -> V^T[d][key0], V^T[d][key0 + 1]
             const unsigned a = vreg[0][w], b = vreg[1][w];
@@ -164,12 +227,21 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.0f; o[1][r] = 0.0f; }
     float m = ATT_NEG, lsum = 0.0f;
     const int nch = (len + ATT_CHUNK - 1) / ATT_CHUNK;
+#if ATT_DMA
+    dma_chunk(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
     load_chunk(0);
     store_chunk(0);
+#endif
     __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
         const int cur = ch & 1;
+#if ATT_DMA
+        if (ATT_ABL != 4 && ATT_ABL != 7 && ch + 1 < nch) dma_chunk(ch + 1, cur ^ 1);      // (everybody left that buffer at the previous chunk's barrier)
+#else
         if (ATT_ABL != 4 && ATT_ABL != 7 && ch + 1 < nch) load_chunk(ch + 1);
+#endif
         // S^T tiles: keys t*32 + [0,32) of the chunk x the wave's 32 queries
         f32x16 s[2];
 #pragma unroll
@@ -178,7 +250,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
             for (int r = 0; r < 16; ++r) s[t][r] = 0.0f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
+#if ATT_SWZL
+                const v4u kf = *reinterpret_cast<const v4u*>(&k_lds[ATT_ABL == 4 ? 0 : cur][(t * 32 + c) * 64 + (((ks * 2 + g) ^ ATT_SWZ(c)) * 8)]);
+#else
                 const v4u kf = *reinterpret_cast<const v4u*>(&k_lds[ATT_ABL == 4 ? 0 : cur][(t * 32 + c) * ATT_KSTR + ks * 16 + g * 8]);
+#endif
                 if (ATT_ABL != 2) s[t] = CmrBlk<DT>::mma(kf, qf[ks], s[t]);
                 else s[t][ks] += __uint_as_float(kf[0] & 0x3F800000u);
             }
@@ -200,6 +276,25 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
         const float mn = fmaxf(m, cm);
         const float alpha = __builtin_amdgcn_exp2f((m - mn) * sc);
         const float msc = mn * sc;
+        // two scores per instruction where the ISA has a packed form (v_pk_fma_f32, v_pk_add_f32: the kernel is bound by its VALU work —
+        // 155 instructions per 16 MFMAs and chunk, 64 of them these multiply-adds and sums)
+#if ATT_PK
+        typedef float att_f2 __attribute__((ext_vector_type(2)));
+        att_f2 ps2 = {0.0f, 0.0f};
+        const att_f2 sc2 = {sc, sc}, nm2 = {-msc, -msc};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                att_f2 x = {s[t][r], s[t][r + 1]};
+                x = __builtin_elementwise_fma(x, sc2, nm2);
+                if (ATT_ABL != 1) { x[0] = __builtin_amdgcn_exp2f(x[0]); x[1] = __builtin_amdgcn_exp2f(x[1]); }
+                s[t][r] = x[0];
+                s[t][r + 1] = x[1];
+                ps2 += x;
+            }
+        const float ps = ps2[0] + ps2[1];
+#else
         float ps = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -209,6 +304,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
                 s[t][r] = p;
                 ps += p;
             }
+#endif
         // (after the first chunks the running maxima rarely move: alpha is exactly 1.0 in every lane then, and x * 1.0 == x)
         if (!ATT_SKIP_RESCALE || __any(mn != m)) {
             lsum = fmaf(lsum, alpha, ps);
@@ -235,10 +331,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
                     // the A operand of lane l: V[kb + {0..3, 8..11}][dt*32 + c].  A transposing read hands lane i of a 16-lane group column i of the
                     // 4 x 16 block whose row (i >> 2), columns 4 * (i & 3) .. + 3 that lane addresses (tools/probe/tr_probe.hip): rows = keys
                     // kb .. kb + 3, columns = d of this group's sixteen lanes
+#if ATT_SWZL
+                    // (row + 8 flips bit 2 of u = bit 1 of f: the second read's slot is the first one's ^ 2)
+                    const int vrow_ = kb + ((lane & 15) >> 2);
+                    const int vslot_ = (dt * 4 + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1)) ^ ATT_SWZ(vrow_);
+                    const unsigned short* vblk = &v_lds[cur][vrow_ * 64 + vslot_ * 8 + 4 * (lane & 1)];
+                    const unsigned short* vblk8 = &v_lds[cur][(vrow_ + 8) * 64 + (vslot_ ^ 2) * 8 + 4 * (lane & 1)];
+#else
                     const unsigned short* vblk = &v_lds[cur][(kb + ((lane & 15) >> 2)) * ATT_VSTR + dt * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)];
+                    const unsigned short* vblk8 = vblk + 8 * ATT_VSTR;
+#endif
                     typedef __attribute__((address_space(3))) att_v4s* lds_v4s;
                     const att_v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)vblk);
-                    const att_v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(vblk + 8 * ATT_VSTR));
+                    const att_v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)vblk8);
                     const uint2 lo = __builtin_bit_cast(uint2, lo4), hi = __builtin_bit_cast(uint2, hi4);
 #else
                     const unsigned short* vrow = &v_lds[cur][(dt * 32 + c) * ATT_VSTR + kb];
@@ -250,7 +355,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : ATT_MIN_WG) void attn_fwd_ke
                 }
             }
         if (ATT_ABL != 4) {
+#if ATT_DMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of the next chunk have landed; the barrier says everybody's have
+#else
             if (ch + 1 < nch) store_chunk(cur ^ 1);
+#endif
             if (ATT_ABL != 5) __syncthreads();
         }
     }
