@@ -840,14 +840,9 @@ def main():
                                                                      dual=bool(sh2.local.get_option("pipe_dual_scan_active" if b2 <= 64 else "pipe_dual_scan_wide_active")))
             if name == "config2":
                 try:
-                    lat = single_query_latency(torch, args, device)
-                    sh2.local.search(qh[:1], args.k)
-                    t1 = []
-                    for _ in range(30):
-                        t0 = time.perf_counter()
-                        sh2.local.search(qh[:1], args.k)
-                        t1.append(time.perf_counter() - t0)
-                    lat["rows"][str(rows2)] = float(np.median(t1) * 1e6)
+                    # (every size on an index of its own, as tools/latency.py measures it: the pipelined shard above still has its scans' event timing
+                    # switched on, and two event records around every n-th scan are part of such a call)
+                    lat = single_query_latency(torch, args, device, sizes=(6, 1000, 10_000, 100_000, rows2))
                     extra["single_query_latency"] = lat
                 except Exception as e:
                     extra["single_query_latency"] = {"error": repr(e)[:300]}

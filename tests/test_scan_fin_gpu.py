@@ -228,3 +228,18 @@ def test_polled_done_word_from_sixteen_threads_and_on_overflow():
     for i in range(12):
         assert _same(tight.search(Q[i:i + 1 + i % 4], 20), ref[i])
     poll.close(); tight.close()
+
+
+def test_polled_calls_by_the_ten_thousand_never_wait_for_the_stream():
+    """40 000 polled calls in a row on one workspace — the runtime never sees a stream wait from this thread and has to recycle its launch
+    resources (signals, kernel-argument chunks) on its own — and the last call still returns what the first one did."""
+    X, Q = _mk(2000, 64, 4, seed=9)
+    idx = _index("bf16", X, {"sync_poll": 1})
+    first = idx.search(Q[:1], 10)
+    first_sc = idx.scores(Q[:1])
+    for _ in range(20_000):
+        idx.search(Q[:1], 10)
+        idx.scores(Q[:1])
+    assert _same(idx.search(Q[:1], 10), first)
+    assert np.array_equal(idx.scores(Q[:1]), first_sc)
+    idx.close()

@@ -4,7 +4,7 @@
 # configuration, SQ counters + traffic of the wide kernel.  Everything lands in gpurun_out/<round>_profiles/: the summaries AND a
 # compressed per-dispatch CSV of every database (tools/rocpd_dump.py), which is what gets copied into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-ROUND=${ROUND:-r5}
+ROUND=${ROUND:-r6}
 O=$R/gpurun_out/${ROUND}_profiles; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $O/kt -o w -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc > $O/bench_under_trace.json 2> $O/kt.err
