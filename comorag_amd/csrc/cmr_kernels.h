@@ -84,6 +84,7 @@ struct CmrScanArgs {
 #define CMR_FIN_STATE 96      // result state: 1 = the scan wrote the final results itself, 2 = a list overflowed (the merge launch decides)
 #define CMR_FIN_OVER 128      // some workgroup's staging area overflowed
 #define CMR_FIN_DBG 136
+#define CMR_FIN_DBG2 196      // development builds: per-wave sums (behind CMR_FIN_CLAIM's word, same line)
 #define CMR_FIN_PUB 160       // supplying workgroups whose maxima are written through
 #define CMR_FIN_CLAIM 192     // queries whose threshold somebody has taken on
 #define CMR_FIN_MAX_QUERIES 16

@@ -367,6 +367,14 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     }
     u64* list_w = TOPK ? P.lists + gwl * NQ * CAP : nullptr;
     int fin_phase = 0;      // FIN: 0 = first panel pending, 1 = waiting for the published thresholds, 2 = adopted
+#ifdef CMR_FIN_DEBUG
+    unsigned dbg_t_slow = 0, dbg_n_slow = 0, dbg_n_whole = 0, dbg_t_thr = 0, dbg_t_epi = 0;      // ticks (10 ns) / counts of this wave
+#define CMR_DBG_T0 const unsigned dbg_t0_ = (unsigned)wall_clock64();
+#define CMR_DBG_ADD(V) V += (unsigned)wall_clock64() - dbg_t0_;
+#else
+#define CMR_DBG_T0
+#define CMR_DBG_ADD(V)
+#endif
     if constexpr (FIN) {
         // The workgroups that do not supply the thresholds look for them before they start: the second round of workgroups (a CU
         // holds one at a time) finds them published and never scans without.  fin_spin > 0 makes wave 0 look again every ~1.5 us
@@ -526,12 +534,21 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                                 for (int r = 0; r < 16; ++r) dst[r] = cmr_make_key(acc[0][r], (unsigned)(row0 + cmr_acc_row(r, lane)));
                                 if (lane < 32) __hip_atomic_store(&cnt_w[ql], c0 + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
+#ifdef CMR_FIN_DEBUG
+                            ++dbg_n_whole;
+#endif
                             continue;
                         }
                     }
-                    if (__any(mx >= tau_f[t]))
+                    if (__any(mx >= tau_f[t])) {
+#ifdef CMR_FIN_DEBUG
+                        ++dbg_n_slow;
+#endif
+                        CMR_DBG_T0
                         topk_slow_path<CAP>(acc[t], row0, P.nrows, P.k, tau_key[t], tau_f[t], cnt_w + t * 32,
                                             list_w + (size_t)t * 32 * CAP, stage, lane);
+                        CMR_DBG_ADD(dbg_t_slow)
+                    }
                 }
                 if constexpr (FIN) {
                     // Finishing stage, part 1 — thresholds without a sampling launch.  Every wave starts with no threshold (its
@@ -549,6 +566,9 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                     // held — or spilled — across it)
                     int lane_o = lane;
                     asm volatile("" : "+v"(lane_o));
+                    CMR_DBG_T0
+                    const int fin_phase_was_ = fin_phase;
+                    (void)fin_phase_was_;
                     if (fin_phase == 0) {
                         // the per-query maxima of this wave's first panel go to LDS; the workgroup's last wave takes a ticket, and the first
                         // fin_wgs workgroups to get one — the FASTEST, whichever they are: the slowest of a fixed set of 128 was through its
@@ -623,6 +643,7 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                             if (cq < nq_g) fin_threshold(P.fin_pmax, P.fin_wgs * CMR_SCAN_WAVES, P.k, P.fin_tau, &P.fin[CMR_FIN_READY], stage, cq, lane_o);
                         }
                     }
+                    if constexpr (FIN) { if (fin_phase_was_ != 2) { CMR_DBG_ADD(dbg_t_thr) } }
                 }
             } else {
                 const long long row = row0 + (lane & 31);
@@ -673,6 +694,13 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
     }
     if constexpr (FIN) {
         if (lane == 0) { CMR_FIN_STAMP_MIN(P, 7); CMR_FIN_STAMP_MAX(P, 8); }      // first / last wave out of its scan loop
+#ifdef CMR_FIN_DEBUG
+        const unsigned dbg_t_p2_ = (unsigned)wall_clock64();
+        if (lane == 0) {
+            atomicAdd((unsigned*)&P.fin[CMR_FIN_DBG2 + 0], dbg_t_slow); atomicAdd((unsigned*)&P.fin[CMR_FIN_DBG2 + 1], dbg_n_slow);
+            atomicAdd((unsigned*)&P.fin[CMR_FIN_DBG2 + 2], dbg_n_whole); atomicAdd((unsigned*)&P.fin[CMR_FIN_DBG2 + 3], dbg_t_thr);
+        }
+#endif
         // Finishing stage, part 2 — the final selection without a merge launch.  Every wave stages the keys of its lists that beat
         // its FINAL threshold (any threshold a wave holds is a valid lower bound of the global k-th best: nothing that can win is
         // dropped) in its LDS scratch; the workgroup appends them to one dense list per query with ONE device atomic per query,
@@ -757,6 +785,9 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fin_sh[0] = atomicAdd(&P.fin[CMR_FIN_WGS], 1);
             CMR_FIN_STAMP_MIN(P, 9); CMR_FIN_STAMP_MAX(P, 10);      // first / last ticket
+#ifdef CMR_FIN_DEBUG
+            atomicAdd((unsigned*)&P.fin[CMR_FIN_DBG2 + 4], (unsigned)wall_clock64() - dbg_t_p2_);      // hand-over of this workgroup (its wave 0: scan end -> ticket)
+#endif
         }
         __syncthreads();
         if (fin_sh[0] != (int)gridDim.x - 1) return;
@@ -835,6 +866,10 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                        us(T[1]), us(T[2]), us(T[3]), us(T[4]), us(T[5]), us(T[6]), us(T[7]), us(T[8]), us(T[9]), us(T[10]), us(te));
                 printf("FIN    first supplying wave through its first panel %.1f | supplying workgroups complete: 1st %.1f, 16th %.1f, 32nd %.1f, 64th %.1f, 96th %.1f, all %d %.1f\n",
                        us(T[11]), us(T[12]), us(T[13]), us(T[14]), us(T[15]), us(T[16]), P.fin_wgs, us(T[2]));
+                const unsigned* T2 = (const unsigned*)&P.fin[CMR_FIN_DBG2];
+                printf("FIN    per wave (W = %d): slow-path entries %.2f taking %.2f us, whole panels %.2f, threshold logic %.2f us | hand-over per workgroup %.2f us\n", W,
+                       (float)T2[1] / W, T2[0] * 0.01f / W, (float)T2[2] / W, T2[3] * 0.01f / W, T2[4] * 0.01f / (int)gridDim.x);
+                for (int i = 0; i < 5; ++i) P.fin[CMR_FIN_DBG2 + i] = 0;
                 for (int i = 0; i < 17; ++i) P.fin[CMR_FIN_DBG + 2 + i] = (i == 0 || i == 3 || i == 5 || i == 7 || i == 9 || i == 11) ? -1 : 0;
             }
             P.fin[CMR_FIN_DBG] = 0; P.fin[CMR_FIN_DBG + 1] = 0;
