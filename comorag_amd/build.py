@@ -273,6 +273,50 @@ def audit_wide(asm_text: str) -> dict:
     return result
 
 
+def audit_asm_sgpr_hazard(asm_text: str) -> list:
+    """gfx9 needs five wait states between a VALU instruction that writes an SGPR (v_readlane / v_readfirstlane: how hipcc brings a SPILLED
+    SGPR back) and a vector-memory instruction that reads that SGPR as its address.  hipcc pads them for its own instructions and not for
+    the ones inside an inline-asm statement: the scan kernel's hand-written loads take their base as an "s" operand, and in a variant with
+    a hundred spilled SGPRs the reload can sit directly in front of the statement (round 6: the finishing stage's READY hint faulted on a
+    stale base in the 8-block-ring variants).  Returns (kernel, line number, writer, asm instruction) for every such pair in the listing —
+    the build fails on any.  An `s_nop n` counts n + 1 states, every other instruction one."""
+    lines = asm_text.split("\n")
+
+    def is_instr(t: str) -> bool:
+        t = t.strip()
+        return bool(t) and not t.startswith((";", ".", "//")) and not t.endswith(":")
+
+    found, kern, in_asm = [], None, False
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            kern = m.group(1)
+        if "ASMSTART" in l:
+            in_asm = True
+            continue
+        if "ASMEND" in l:
+            in_asm = False
+            continue
+        if not in_asm or not re.search(r"\b(global|buffer|flat|scratch)_(load|store|atomic)", l):
+            continue
+        sregs = set()
+        for a, b in re.findall(r"\bs\[(\d+):(\d+)\]", l):
+            sregs.update(range(int(a), int(b) + 1))
+        sregs.update(int(x) for x in re.findall(r"\bs(\d+)\b", l))
+        ws, k = 0, i - 1
+        while k >= 0 and ws < 5:
+            t = lines[k].strip()
+            if is_instr(t):
+                w = re.match(r"v_read(?:first)?lane_b32 s(\d+),", t)
+                if w and int(w.group(1)) in sregs:
+                    found.append((kern, i + 1, t, l.strip()))
+                    break
+                n = re.match(r"s_nop (\d+)", t)
+                ws += int(n.group(1)) + 1 if n else 1
+            k -= 1
+    return found
+
+
 def _run(cmd, cwd=None):
     r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
@@ -315,6 +359,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
         bad = {k: v for k, v in wide.items() if v}
         if bad:             # there is no second implementation to fall back to: refuse to ship a wide kernel that spills
             raise RuntimeError(f"wide-kernel ISA audit failed: {bad}")
+        haz = audit_asm_sgpr_hazard(open(asm_file).read())
+        if haz:             # a stale address is a memory fault or — worse — a read of something else
+            raise RuntimeError(f"inline-asm vector-memory instruction reads an SGPR a VALU instruction wrote < 5 wait states before: {haz[:4]}")
         # 2. audit table
         rows = ",\n".join(f"    {{{dt}, {nqt}, {cap}, {ring}, {mode}, {1 if ok else 0}}}"
                           for (dt, nqt, cap, ring, mode), ok in sorted(audit.items()))

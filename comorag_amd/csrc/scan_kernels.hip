@@ -39,6 +39,9 @@
 // mid-size or large corpus: the sampling scan, its merge and the candidate merge are a chain of dependent launches around a
 // short scan there) — see "finishing stage" in scan_kernel
 #define MODE_FIN 2
+#ifndef CMR_FIN_HINT
+#define CMR_FIN_HINT 1     // finishing stage, hand-counted ring: the READY word is asked for inside the ring's own load sequence and only hints at the proper look (below)
+#endif
 
 // Cache policy of the corpus stream's loads: non-temporal.  Every byte of the corpus is read once per launch by one CU,
 // so keeping the lines in L2 / MALL only evicts what the other kernels of the pipeline use; measured with
@@ -482,7 +485,27 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
         const long long ngroups = (long long)(p1 - p0) * GPP;
         int gi = 0;
         int p = p0;
+        [[maybe_unused]] unsigned fin_hint = 0u, fin_zoff = 0u;
+        [[maybe_unused]] bool fin_hint_valid = false;
+        asm volatile("" : "+v"(fin_zoff));
         for (long long it = -1; it < ngroups; ++it) {
+            if constexpr (FIN && ASMRING && CMR_FIN_HINT) {
+                // A wave that has not adopted the thresholds yet asks for the READY word at the START of a panel's last group — one more load in
+                // the ring's own sequence, nothing waits for it: loads return in order, so the counted waits of the sixteen ring steps that follow
+                // retire it on the way.  At the panel end the value is only a HINT: the proper device-scope load (whose s_waitcnt vmcnt(0) drains
+                // the whole ring: 3-4 us without a request from this wave, at every panel end until the adoption) is made only when the hint says
+                // there is something to fetch.  Whatever the register holds if the compiler ever moved it — an old value, anything — costs one
+                // look too many or one panel's delay, never a result.
+                // (one or two queries only: with more, the thresholds are taken query by query by the waves that pass a panel end after the
+                // publication, and a wave that looks at a third-of-a-panel-old hint joins that later — 8 queries: +10 us per call, measured)
+                if (fin_phase == 1 && it >= 0 && gi == GPP - 1 && nq_g <= 2) {
+                    // (s_nop 4: with 100 SGPRs spilled the base may have come back through v_readlane in the instruction before — a VALU write of an
+                    // SGPR that a VMEM instruction reads as its address needs five wait states, and hipcc pads none for inline asm: the first
+                    // version faulted on exactly that in the 8-block-ring variant)
+                    asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 offset:%3 sc1" : "=v"(fin_hint) : "v"(fin_zoff), "s"(P.fin), "n"(CMR_FIN_READY * 4) : "memory");
+                    fin_hint_valid = true;
+                }
+            }
             {
                 const v4u* qg = qf + (size_t)gi * R * 64 + lane;
                 CMR_RING_ALL(CMR_RING_STEP)
@@ -626,7 +649,18 @@ __global__ __launch_bounds__(CMR_SCAN_THREADS, 2) void scan_kernel(ScanP P) {
                         fin_phase = 1;
                     }
                     // (a wave whose first panel ends after the thresholds were published adopts them here and now, not a panel later)
-                    if (fin_phase == 1) {
+                    bool fin_look = fin_phase == 1;
+                    if constexpr (ASMRING && CMR_FIN_HINT) {
+                        if (fin_look && fin_hint_valid) {        // (the hint of this panel's last group: see the top of the ring loop)
+                            unsigned h_ = fin_hint;
+                            asm volatile("" : "+v"(h_));
+                            const int hs = __builtin_amdgcn_readfirstlane((int)h_);
+                            const int full_ = (int)((1u << nq_g) - 1u);
+                            fin_look = hs < 0 || (hs & full_) == full_;      // published (bit 31: a threshold may be there to claim) or complete
+                        }
+                        fin_hint_valid = false;
+                    }
+                    if (fin_look) {
                         const int rd = __hip_atomic_load(&P.fin[CMR_FIN_READY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const int full = (int)((1u << nq_g) - 1u);
                         if ((rd & full) == full) {

@@ -66,3 +66,26 @@ def test_scratch_traffic_fails_the_variant():
 def test_wrong_number_of_ring_registers_fails():
     asm = _kernel().replace("global_load_dwordx4 v[38:41]", "global_load_dwordx4 v[34:37]")
     assert audit_ring(asm) == {KEY: False}
+
+
+def test_valu_written_sgpr_in_front_of_an_asm_load_is_flagged_and_five_wait_states_clear_it():
+    """build.audit_asm_sgpr_hazard: hipcc brings a spilled SGPR back with v_readlane and pads no wait states in front of an inline-asm
+    vector-memory instruction that reads it as its address (round 6: the READY hint of the finishing stage faulted on exactly that)."""
+    from comorag_amd.build import audit_asm_sgpr_hazard
+    bad = """_Z4kernv:
+	v_readlane_b32 s12, v136, 16
+	v_readlane_b32 s13, v136, 17
+	;;#ASMSTART
+	global_load_dword v121, v97, s[12:13] offset:0x80 sc1
+	;;#ASMEND
+	s_endpgm
+"""
+    hits = audit_asm_sgpr_hazard(bad)
+    assert len(hits) == 1 and hits[0][0] == "_Z4kernv" and "v_readlane_b32 s13" in hits[0][2]
+    good = bad.replace("\tglobal_load_dword", "\ts_nop 4\n\tglobal_load_dword")
+    assert audit_asm_sgpr_hazard(good) == []
+    # compiler-issued loads (outside an asm statement) are hipcc's own business; four plain instructions + the nop-less load are one state short
+    assert audit_asm_sgpr_hazard(bad.replace(";;#ASMSTART\n", "").replace(";;#ASMEND\n", "")) == []
+    spaced = bad.replace("\t;;#ASMSTART", "\ts_mov_b32 s1, 0\n\ts_mov_b32 s2, 0\n\ts_mov_b32 s3, 0\n\ts_mov_b32 s4, 0\n\t;;#ASMSTART")
+    assert len(audit_asm_sgpr_hazard(spaced)) == 1
+    assert audit_asm_sgpr_hazard(spaced.replace("s_mov_b32 s4, 0", "s_mov_b32 s4, 0\n\ts_mov_b32 s5, 0")) == []
