@@ -33,6 +33,17 @@
  * wire are RAW inner products; ComoRAG's min-max normalisation (utils/misc_utils.py:141-150) is
  * applied by the Python layer from out_min/out_max so its formula stays textually the
  * reference's.  Inputs must be finite (checked: CMR_ERR_NONFINITE).
+ *
+ * Encoder stages (cmr_encoder_*): the library computes the model's own functions — exact (erf) GELU, fp32 LayerNorm statistics, masked
+ * mean-pool + L2 normalisation.  The Python layer can OPT IN (`embedding_gelu = "epilogue"`) to hipBLASLt's bias + GELU GEMM epilogue,
+ * whose GELU is the TANH form (<= 4.8e-4 per activation from the erf form: a different function from BGEEmbedding.py:120's, inside the
+ * 1e-3 bar on the tested weights, never the default).
+ *
+ * Synchronous host-buffer calls (cmr_index_search, cmr_index_search_min_score, cmr_index_scores, and cmr_mindex_* on top of them) return
+ * as soon as the results are in the caller's buffers: where the search's last kernel can report it, the host polls a word that kernel
+ * stores behind its results in a pinned, device-mapped buffer instead of waiting for the stream (option sync_poll, default 1; ~5 us per
+ * call).  The stream itself may still be finishing that kernel's epilogue when the call returns — invisible to the caller: every later
+ * call on the index is ordered behind it.
  */
 #ifndef COMORAG_HIP_H
 #define COMORAG_HIP_H
@@ -159,7 +170,7 @@ int32_t cmr_index_set_id_blocks(cmr_index_t* idx, int32_t n_blocks, const int64_
  * more than 64 queries as narrow passes), scan_no_tiny / scan_no_small / small_max_panels / tiny_multi (single-launch
  * paths), zero_copy, sample_single, sample_single_max, sample_tau_in_scan, sample_div, sample_maxmul, scan_fin (0: small synchronous
  * batches run the sampling / scan / merge chain instead of the scan with the finishing stage) / scan_fin_queries (<= 16) /
- * scan_fin_dense / scan_fin_spin, sync_poll, wide_mode (1: register-resident wide kernel | 2: query-split grid of the narrow kernel),
+ * scan_fin_dense / scan_fin_spin / scan_fin_suppliers / scan_fin_cap, sync_poll (0: synchronous calls wait for the stream), wide_mode (1: register-resident wide kernel | 2: query-split grid of the narrow kernel),
  * stream_nt, pipe_reserve_cus, pipe_slots (2..4), wide_waves (4 | 8:
  * waves per workgroup of the batch-256 kernel at 768-d; 8 only in builds with -DCMR_WIDE8), pipe_cu_mask (0: never | 1 | 2: every scan; default: scans shorter than ~1 ms) and
  * pipe_dual_scan (0 | 1; default: scans shorter than ~1 ms) — the pipelined search's streams with explicit CU masks (scans
