@@ -34,8 +34,8 @@
  * applied by the Python layer from out_min/out_max so its formula stays textually the
  * reference's.  Inputs must be finite (checked: CMR_ERR_NONFINITE).
  *
- * Encoder stages (cmr_encoder_*): the library computes the model's own functions — exact (erf) GELU, fp32 LayerNorm statistics, masked
- * mean-pool + L2 normalisation.  The Python layer can OPT IN (`embedding_gelu = "epilogue"`) to hipBLASLt's bias + GELU GEMM epilogue,
+ * Encoder stages (cmr_encoder_*): the library computes the model's own functions — softmax attention, fp32 LayerNorm statistics, masked
+ * mean-pool + L2 normalisation; the FFN's GELU runs in PyTorch, by default in the model's exact (erf) form.  The Python layer can OPT IN (`embedding_gelu = "epilogue"`) to hipBLASLt's bias + GELU GEMM epilogue,
  * whose GELU is the TANH form (<= 4.8e-4 per activation from the erf form: a different function from BGEEmbedding.py:120's, inside the
  * 1e-3 bar on the tested weights, never the default).
  *
