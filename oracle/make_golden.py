@@ -52,9 +52,77 @@ class FakeEmbedder:
         return torch.from_numpy(self.batch_encode(texts))
 
 
+TRI_CORPUS = {
+    "chunk": [f"chunk {i}: " + w for i, w in enumerate(
+        ["cinders by the hearth", "a glass slipper on the stairs", "the ball at midnight", "two stepsisters at the mirror",
+         "a pumpkin coach and six mice", "the prince's search through the town", "a hazel tree on the grave", "white doves at the window",
+         "the stepmother's orders", "lentils in the ashes", "the third night of the feast", "the wedding procession"])],
+    "entity": ["cinderella", "prince", "stepmother", "slipper", "pumpkin", "doves"],
+    "fact": [str(t) for t in [("cinderella", "lost", "slipper"), ("prince", "found", "slipper"), ("stepmother", "hid", "cinderella"),
+                              ("pumpkin", "became", "coach"), ("doves", "helped", "cinderella"), ("prince", "married", "cinderella"),
+                              ("stepsisters", "envied", "cinderella")]],
+    "summary": ["summary: the ball", "summary: the search", "summary: the wedding", "summary: the household"],
+    "level_0": [f"timeline window {i}: " + w for i, w in enumerate(["before the ball", "the three nights", "midnight", "the search", "the fitting", "the wedding"])],
+}
+TRI_QUERIES = ["who lost a slipper?", "what became a coach?", "who helped cinderella?", "where did the doves sit?"]
+TRI_CONFIG = {"need_cluster": True, "index_dtype": "f32", "linking_top_k": 5, "qa_ver_top_k": 5, "qa_sem_top_k": 2, "qa_epi_top_k": 3}
+TRI_POOL = {"VER": [("chunk", 1), ("chunk", 5)], "SEM": [("summary", 1)], "EPI": [("level_0", 3)]}      # what the memory pool already holds: (store, text index)
+
+
+def tri_bare_rag(ComoRAG, Store, emb, tmp):
+    """A real ComoRAG instance without its constructor (LLM clients, igraph, OpenIE) carrying exactly what ComoRAG.tri_retrieve
+    (ComoRAG.py:456-554) reads: five stores, the graph's vertex names, the timeline summarizer's embedder — and a reranker (an LLM
+    filter in the reference, rerank.py) that keeps no fact, i.e. the loop's dense-retrieval branch (:489-491)."""
+    import types
+    st = {}
+    for ns, texts in TRI_CORPUS.items():
+        st[ns] = Store(emb, os.path.join(tmp, ns), 8, ns)
+        st[ns].insert_strings(texts)
+    rag = ComoRAG.__new__(ComoRAG)
+    rag.global_config = types.SimpleNamespace(**TRI_CONFIG)
+    rag.embedding_model = emb
+    rag.ver_embedding_store, rag.entity_embedding_store = st["chunk"], st["entity"]
+    rag.fact_embedding_store, rag.sem_embedding_store = st["fact"], st["summary"]
+    rag.graph = types.SimpleNamespace(vs=[{"name": n} for n in st["entity"].get_all_ids() + st["chunk"].get_all_ids()])
+    rag.ready_to_retrieve = False
+    rag.level_store = st["level_0"]
+    rag.timeline_summarizer = types.SimpleNamespace(summary_store=types.SimpleNamespace(embedding_model=emb))
+    rag.rerank_facts = lambda query, scores: ([], [], {"facts_before_rerank": [], "facts_after_rerank": []})
+    return rag, st
+
+
+def tri_pool(NodeType, st):
+    import types
+    held = {getattr(NodeType, kind): [st[ns].text_to_hash_id[TRI_CORPUS[ns][i]] for ns, i in items] for kind, items in TRI_POOL.items()}
+    return types.SimpleNamespace(get_all_hashes=lambda: held)
+
+
+def golden_tri_retrieve(m):
+    """tests/golden/tri_retrieve.json: what the reference's OWN tri_retrieve returns for a seeded toy corpus (real ComoRAG class, real
+    EmbeddingStore, real get_similar_summaries, numpy scores; the fake embedder for BGE).  The fixture is data: texts in, texts out."""
+    import tempfile, shutil
+    tmp = tempfile.mkdtemp(prefix="cmr_tri_")
+    try:
+        emb = FakeEmbedder(32)
+        rag, st = tri_bare_rag(m["ComoRAG"].ComoRAG, m["embedding_store"].EmbeddingStore, emb, tmp)
+        pool = tri_pool(m["memory_utils"].NodeType, st)
+        out = {"corpus": TRI_CORPUS, "queries": TRI_QUERIES, "config": TRI_CONFIG, "pool": {k: [list(x) for x in v] for k, v in TRI_POOL.items()}, "docs": []}
+        for q in TRI_QUERIES:
+            docs, _ = rag.tri_retrieve(q, pool)
+            out["docs"].append(docs)
+        with open(os.path.join(OUT, "tri_retrieve.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m = ref_modules()
+    if "--only-tri-retrieve" in sys.argv:
+        golden_tri_retrieve(m)
+        print("wrote", os.path.join(OUT, "tri_retrieve.json"))
+        return
     ComoRAG = m["ComoRAG"].ComoRAG
     rng = np.random.default_rng(20250829)
 
@@ -206,6 +274,7 @@ def main():
         json.dump({"contents": [f"{n.probe} {n.cue}" for n in nodes], "probe": "probe 1",
                    "selected": [nodes.index(s) for s in sel]}, f, indent=1)
 
+    golden_tri_retrieve(m)
     print("golden fixtures written to", OUT, sorted(os.listdir(OUT)))
 
 

@@ -336,3 +336,45 @@ def test_embedding_cache_files_are_interchangeable_with_the_reference_wrapper(tm
     assert calls == [] and torch.equal(d, e)
     our_w2(prompts=["delta"], instruction="other", max_length=16)                # a different instruction is a different key
     assert calls == [["delta"]]
+
+
+def test_the_real_tri_retrieve_loop_runs_on_the_hooks(tmp_path, golden_dir, fake_embedder, numpy_index_cls, monkeypatch):
+    """ComoRAG.tri_retrieve (ComoRAG.py:456-554) — the reference's OWN method, unmodified — on an instance whose stores are this package's
+    EmbeddingStore and whose numeric call sites are rebound by hooks.install (the device index replaced by conftest.NumpyIndex, the module's
+    get_similar_summaries by retrieval's): the three layers it returns must be the ones the untouched reference returns on its own stores,
+    live and as recorded in tests/golden/tri_retrieve.json (the fixture the GPU tier checks the HIP index against)."""
+    from oracle.ref_loader import ref_modules
+    from oracle.make_golden import tri_bare_rag, tri_pool, TRI_QUERIES
+    from comorag_amd import hooks
+    from comorag_amd.embedding_store import EmbeddingStore
+    m = ref_modules()
+    ComoRAG, NodeType = m["ComoRAG"].ComoRAG, m["memory_utils"].NodeType
+    gold = json.load(open(os.path.join(golden_dir, "tri_retrieve.json")))
+    assert gold["queries"] == TRI_QUERIES
+
+    def factory(mat, dtype, device):
+        mat = np.asarray(mat, np.float32)
+        if mat.ndim != 2 or len(mat) == 0:
+            return None
+        ix = numpy_index_cls(mat.shape[1], dtype, device)
+        ix.append(mat)
+        return ix
+
+    # (the level store's HBM mirror — EmbeddingStore.device_index, what get_similar_summaries scores against — is the numpy stand-in too)
+    monkeypatch.setattr("comorag_amd.multi_index.make_index", lambda dim, dtype, **kw: numpy_index_cls(dim, dtype, kw.get("device", 0)))
+    ref, ref_st = tri_bare_rag(ComoRAG, m["embedding_store"].EmbeddingStore, fake_embedder, str(tmp_path / "ref"))
+    ours, our_st = tri_bare_rag(ComoRAG, EmbeddingStore, fake_embedder, str(tmp_path / "ours"))
+    mod = sys.modules[ComoRAG.__module__]
+    keep = mod.get_similar_summaries
+    try:
+        want = [ref.tri_retrieve(q, tri_pool(NodeType, ref_st))[0] for q in TRI_QUERIES]          # the untouched reference, live
+        assert want == gold["docs"]
+        hooks.install(ours, index_factory=factory, patch_module_functions=True)                        # rebinds the module's get_similar_summaries too
+        assert mod.get_similar_summaries is not keep
+        got = [ours.tri_retrieve(q, tri_pool(NodeType, our_st))[0] for q in TRI_QUERIES]
+        assert got == gold["docs"]
+        assert ours.tri_retrieve.__func__ is ComoRAG.tri_retrieve                                      # the loop itself is the reference's
+    finally:
+        mod.get_similar_summaries = keep
+        if hasattr(mod, "retrieve_knn"):
+            mod.retrieve_knn = m["embed_utils"].retrieve_knn

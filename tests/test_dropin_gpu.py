@@ -555,3 +555,60 @@ def test_full_ranking_with_duplicate_rows_on_both_sides_of_the_device_sort_thres
     ex = orc.exact_scores_f64(X, q[None, :])[0]
     orc.assert_topk_equivalent(ids[:200], ref_ids[:200], ex, 1e-6)
     idx.close()
+
+
+def test_tri_retrieve_layers_on_the_hip_index_vs_the_reference_fixture(golden_dir, tmp_path, fake_embedder):
+    """tests/golden/tri_retrieve.json holds what the reference's own ComoRAG.tri_retrieve (ComoRAG.py:456-554) returned in the build
+    container for a seeded toy corpus (oracle/make_golden.py; the CPU tier runs that very method on this package's stores and hooks,
+    tests/test_binding_reference.py).  The reference tree is not on the GPU box, so here the three layers are assembled from the same
+    pieces on a ComoRAG-shaped object — hooks.install's rebound numeric calls on HIP indexes, this package's EmbeddingStore, retrieval.
+    get_similar_summaries on the level store's HBM mirror — and must be the fixture's, text for text."""
+    from comorag_amd import hooks, retrieval
+    from comorag_amd.embedding_store import EmbeddingStore
+    gold = json.load(open(os.path.join(golden_dir, "tri_retrieve.json")))
+    cfg = gold["config"]
+    st = {}
+    for ns, texts in gold["corpus"].items():
+        st[ns] = EmbeddingStore(fake_embedder, str(tmp_path / ns), 8, ns)
+        st[ns].insert_strings(texts)
+    held = {kind: {st[ns].text_to_hash_id[gold["corpus"][ns][i]] for ns, i in items} for kind, items in gold["pool"].items()}
+
+    class Rag:                                     # the attributes ComoRAG.prepare_retrieval_objects sets (:876-907), from the stores
+        def __init__(self):
+            self.global_config = types.SimpleNamespace(**cfg)
+            self.embedding_model = fake_embedder
+            self.ready_to_retrieve = False
+        def prepare_retrieval_objects(self):
+            self.query_to_embedding = {"triple": {}, "passage": {}}
+            self.passage_node_keys, self.fact_node_keys, self.summary_node_keys = (list(st[n].get_all_ids()) for n in ("chunk", "fact", "summary"))
+            self.passage_embeddings = np.array(st["chunk"].get_embeddings(self.passage_node_keys))
+            self.fact_embeddings = np.array(st["fact"].get_embeddings(self.fact_node_keys))
+            self.summary_embeddings = np.array(st["summary"].get_embeddings(self.summary_node_keys))
+            self.ready_to_retrieve = True
+    import sys
+    sys.modules[Rag.__module__].get_query_instruction = lambda k: k
+    rag = hooks.install(Rag(), patch_module_functions=False)
+
+    def layer(store, keys, ids, top_k, pool_hashes, by_store_order):
+        texts = [store.get_row(keys[i])["content"] for i in ids[:top_k]]
+        texts = [t for t in texts if store.text_to_hash_id[t] not in pool_hashes]
+        if by_store_order:
+            order = store.get_hash_id_to_order()
+            texts = sorted(texts, key=lambda t: order.get(store.text_to_hash_id[t], float("inf")))
+        return texts
+
+    for q, want in zip(gold["queries"], gold["docs"]):
+        if not rag.ready_to_retrieve:
+            rag.prepare_retrieval_objects()
+        rag.get_query_embeddings(q)
+        assert len(rag.get_fact_scores(q)) == len(gold["corpus"]["fact"])          # the link step's input; the reranker (an LLM) kept no fact
+        ids, _ = rag.dense_passage_retrieval(q)
+        ver = layer(st["chunk"], rag.passage_node_keys, ids, cfg["qa_ver_top_k"], held["VER"], True)
+        sids, _ = rag.dense_passage_retrieval(q, need_cluster=True)
+        sem = layer(st["summary"], rag.summary_node_keys, sids, cfg["qa_sem_top_k"], held["SEM"], False)
+        epi_texts, _ = retrieval.get_similar_summaries(query=q, level_store=st["level_0"], embedding_model=fake_embedder, top_k=cfg["qa_epi_top_k"])
+        lv = st["level_0"]
+        epi = [t for t in epi_texts[:cfg["qa_epi_top_k"]] if lv.text_to_hash_id[t] not in held["EPI"]]
+        order = lv.get_hash_id_to_order()
+        epi = sorted(epi, key=lambda t: order.get(lv.text_to_hash_id[t], float("inf")))
+        assert {"veridical": ver, "semantic": sem, "episodic": epi} == want, q
