@@ -751,11 +751,18 @@ hipError_t cmr_launch_embed_layernorm_ragged(const int* ids32, const int* off, c
     return launch_embed_ln_ragged<CMR_DT_F16>(ids32, off, word, pos, type, gamma, beta, eps, rows, L, d, vocab, n_pos, pos_off, out, s);
 }
 
+#ifndef ENC_LN_FEW_ROWS
+#define ENC_LN_FEW_ROWS 256
+#endif
 template <int DT>
 static hipError_t launch_add_ln(const void* y, const void* bias, const void* res, const void* gamma, const void* beta, float eps, long long rows,
                                 int d, void* out, hipStream_t s) {
     const bool al16 = (((uintptr_t)y | (uintptr_t)bias | (uintptr_t)res | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out) & 15) == 0;
-    if (d % 8 == 0 && al16) {
+    // A handful of rows (one short query: 16 .. 128 token rows, 24 / 48 of these launches per encode) is all latency: a WAVE per row (8-byte
+    // vectors, three or four per lane and array at 768 / 1024-d) instead of sixteen lanes per row (six / eight 16-byte vectors per lane) —
+    // a quarter of the dependent loads per lane, four times the waves.  Above, the 16-byte kernel's bandwidth wins (14.6 us at 16 K rows).
+    const bool few = rows <= ENC_LN_FEW_ROWS && d % 4 == 0 && (d / 4 + 63) / 64 <= 8;
+    if (d % 8 == 0 && al16 && !few) {
         const int d8 = d / 8, vpl16 = (d8 + 15) / 16;
         const dim3 grid16((unsigned)((rows + 15) / 16)), block16(256);
 #define ENC_LN16(V)                                                                                                                       \

@@ -50,7 +50,7 @@ def test_attention_kernel_vs_fp32_softmax(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-@pytest.mark.parametrize("d,rows", [(768, 1001), (1024, 64), (256, 7), (40, 130), (2048, 33), (1536, 5)])
+@pytest.mark.parametrize("d,rows", [(768, 1001), (1024, 64), (256, 7), (40, 130), (2048, 33), (1536, 5), (1024, 600), (2048, 300), (256, 257), (768, 256)])
 @pytest.mark.parametrize("parts", ["bias+residual", "residual", "plain"])
 def test_add_layernorm_kernel(dtype, d, rows, parts):
     import torch
@@ -67,7 +67,7 @@ def test_add_layernorm_kernel(dtype, d, rows, parts):
 
 
 @pytest.mark.parametrize("dtype", ["bfloat16", "float16"])
-@pytest.mark.parametrize("b,l,d", [(5, 64, 768), (32, 512, 768), (3, 128, 1024), (2, 16, 256), (4, 48, 2048), (1, 32, 72)])
+@pytest.mark.parametrize("b,l,d", [(5, 64, 768), (32, 512, 768), (3, 128, 1024), (2, 16, 256), (4, 48, 2048), (6, 48, 2048), (1, 32, 72)])
 @pytest.mark.parametrize("normalize", [True, False])
 def test_last_layer_layernorm_with_the_encoder_tail_folded_in(dtype, b, l, d, normalize):
     """cmr_encoder_add_layernorm_pool == cmr_encoder_add_layernorm followed by cmr_pool_l2norm (mean_pooling + F.normalize,
@@ -91,6 +91,12 @@ def test_last_layer_layernorm_with_the_encoder_tail_folded_in(dtype, b, l, d, no
     if normalize:
         want = torch.nn.functional.normalize(want, p=2, dim=1)
     tol = 3e-6 if normalize else 3e-5
+    if b * l <= 256:
+        # A handful of rows: cmr_encoder_add_layernorm runs its wave-per-row kernel (round 6: one short query's 24 / 48 LayerNorm launches at
+        # 5-7 us instead of 9-12), whose fp32 sums run in another order than the folded kernel's sixteen-lane groups: a LayerNorm output now
+        # and then rounds to the neighbouring 16-bit value, and a one-token row shows that unit in the last place undiluted.
+        ulp = 2.0 ** -8 if dtype == "bfloat16" else 2.0 ** -11
+        tol = max(tol, 1.5 * ulp * float(want.abs().max()))
     np.testing.assert_allclose(one.cpu().numpy(), want.cpu().numpy(), atol=tol, rtol=1e-5)
     np.testing.assert_allclose(one.cpu().numpy(), two.cpu().numpy(), atol=tol, rtol=1e-5)
 
