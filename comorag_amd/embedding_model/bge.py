@@ -112,6 +112,11 @@ class _EncodeReplica:
 
 
 class HipBGEEmbeddingModel(BaseEmbeddingModel):
+    # batch_encode overwrites whatever `instruction=` it is handed with the fixed BGE prefix unless the caller passes is_query (nobody does): the
+    # reference's behaviour (BGEEmbedding.py:150-155), kept.  Callers that would encode one text under two instructions (hooks.get_query_embeddings)
+    # may therefore encode it once.
+    instruction_is_ignored = True
+
     def __init__(self, global_config: Optional[BaseConfig] = None, embedding_model_name: Optional[str] = None,
                  model=None, tokenizer=None) -> None:
         """`model` / `tokenizer` may be injected (tests use a seed-initialised BertModel and a synthetic

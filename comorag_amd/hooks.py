@@ -111,10 +111,23 @@ def install(rag, index_dtype: Optional[str] = None, device: int = 0, patch_modul
     def get_query_embeddings(self, queries):
         if isinstance(queries, str):                  # tri_retrieve passes a str (:470): encode it once,
             queries = [queries]                       # not per character — same cached vectors result
+        kinds = (("triple", "query_to_fact"), ("passage", "query_to_passage"))
         for q in queries:
             q = getattr(q, "question", q)
-            _query_vec(self, "triple", q, "query_to_fact")
-            _query_vec(self, "passage", q, "query_to_passage")
+            em = self.embedding_model
+            if getattr(em, "instruction_is_ignored", False) and all(self.query_to_embedding[k].get(q, None) is None for k, _ in kinds):
+                # The reference encodes a new question once per instruction (:937-948) — and its BGE model ignores the instruction it is handed
+                # (BGEEmbedding.py:150-155 overwrite it with the fixed prefix because no caller passes is_query; HipBGEEmbeddingModel keeps the
+                # quirk and says so): both calls run the same prompt through the same deterministic forward.  One forward serves both kinds,
+                # bit for bit what two would return — a short query's encode is ~84 dependent launches, 0.75 ms at BGE-base.
+                from importlib import import_module
+                gqi = import_module(type(self).__module__).get_query_instruction
+                vec = em.batch_encode(q, instruction=gqi(kinds[0][1]), norm=True)
+                for k, _ in kinds:
+                    self.query_to_embedding[k][q] = vec
+                continue
+            for k, key in kinds:
+                _query_vec(self, k, q, key)
 
     def get_fact_scores(self, query: str) -> np.ndarray:
         return retrieval.get_fact_scores(self._hip["fact"], _query_vec(self, "triple", query, "query_to_fact"))

@@ -178,3 +178,53 @@ def test_num_shards_of_the_config_reaches_the_indexes_of_a_real_comorag_instance
         d_ids, d_sc = ref.dense_passage_retrieval(q, need_cluster=True)
         assert c_ids.tolist() == d_ids.tolist()
         np.testing.assert_allclose(c_sc, d_sc, atol=2e-6)
+
+
+def test_a_new_question_is_encoded_once_when_the_model_ignores_its_instruction(fake_embedder, numpy_index_cls):
+    """hooks.get_query_embeddings: the reference encodes a new question once per instruction (ComoRAG.py:921-935), and its BGE model overwrites the
+    instruction it is handed (BGEEmbedding.py:150-155) — two identical forwards.  An embedding model that declares the quirk
+    (`instruction_is_ignored`, HipBGEEmbeddingModel) is called ONCE and both caches hold that row; any other model is called once per kind as
+    before; a question already cached for one kind goes through the per-kind path."""
+    import sys
+    from comorag_amd import hooks
+    rng = np.random.default_rng(0)
+    X, F = rng.standard_normal((9, 32)).astype(np.float32), rng.standard_normal((5, 32)).astype(np.float32)
+
+    class Rag:
+        def __init__(self, emb):
+            self.global_config = types.SimpleNamespace(need_cluster=False, index_dtype="f32")
+            self.embedding_model = emb
+            self.ready_to_retrieve = False
+        def prepare_retrieval_objects(self):
+            self.query_to_embedding = {"triple": {}, "passage": {}}
+            self.passage_embeddings, self.fact_embeddings = X, F
+            self.ready_to_retrieve = True
+    sys.modules[Rag.__module__].get_query_instruction = lambda k: f"<{k}> "
+
+    def factory(mat, dtype, device):
+        ix = numpy_index_cls(np.asarray(mat).shape[1], dtype, device)
+        ix.append(np.asarray(mat, np.float32))
+        return ix
+
+    plain = hooks.install(Rag(fake_embedder), index_factory=factory, patch_module_functions=False)
+    plain.prepare_retrieval_objects()
+    plain.get_query_embeddings("who lost a slipper?")
+    assert fake_embedder.calls == [["who lost a slipper?"], ["who lost a slipper?"]]          # one call per kind: the model says nothing about its instruction
+
+    class Quirky(type(fake_embedder)):
+        instruction_is_ignored = True
+    emb = Quirky(32)
+    rag = hooks.install(Rag(emb), index_factory=factory, patch_module_functions=False)
+    rag.prepare_retrieval_objects()
+    rag.get_query_embeddings(["who lost a slipper?", "what became a coach?"])
+    assert emb.calls == [["who lost a slipper?"], ["what became a coach?"]]                    # once per question
+    t, p = rag.query_to_embedding["triple"], rag.query_to_embedding["passage"]
+    assert all(np.array_equal(t[q], p[q]) and t[q].shape == (1, 32) for q in t) and set(t) == set(p)
+    np.testing.assert_array_equal(t["what became a coach?"][0], emb._vec("what became a coach?"))
+    rag.get_query_embeddings("who lost a slipper?")                                            # memoised
+    rag.dense_passage_retrieval("who lost a slipper?"); rag.get_fact_scores("who lost a slipper?")
+    assert len(emb.calls) == 2
+    rag.query_to_embedding["triple"]["half cached"] = emb._vec("half cached")[None]
+    n0 = len(emb.calls)
+    rag.get_query_embeddings("half cached")
+    assert emb.calls[n0:] == [["half cached"]] and "half cached" in rag.query_to_embedding["passage"]
