@@ -198,6 +198,9 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             if n_rep > 1:
                 for r in range(n_rep):
                     self._replicas.append(_EncodeReplica(self, torch.device("cuda", devs[r % len(devs)]), first=(r == 0)))
+        import collections, threading
+        self._qcache, self._qcache_lock = collections.OrderedDict(), threading.Lock()
+        self._qcache_size = int(cfg_get(self.global_config, "embedding_query_cache", 256) or 0)
         self._cached = bool(cfg_get(self.global_config, "embedding_cache_enabled", False))
         if self._cached:
             path = cfg_get(self.global_config, "embedding_cache_path", None) or "bge_embeddings_cache.db"
@@ -393,6 +396,19 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
         else:
             params["instruction"] = params.get("passage_instruction", BGE_PREFIX)
         batch_size = params.pop("batch_size", 16)
+        # One string — a question: ComoRAG encodes the same question three times per tri_retrieve (once per query instruction, ComoRAG.py:921-935,
+        # and once more for the episodic layer, utils/embed_utils.py get_similar_summaries), and every one of those is the same prompt through the
+        # same deterministic forward (0.75 ms at BGE-base).  The last `embedding_query_cache` single-string results are kept by (prompt, max_length,
+        # normalisation) and handed back as copies; 0 switches it off.  Corpus-sized calls never look here.
+        qkey = None
+        if len(texts) == 1 and not return_device and self._qcache_size > 0 and isinstance(texts[0], str):
+            qkey = (params.get("instruction", "") + texts[0], int(params.get("max_length", 512)), bool(params.get("normalize", True)),
+                    bool(self.embedding_config.norm and not kwargs.get("normalize", True)))
+            with self._qcache_lock:
+                hit = self._qcache.get(qkey)
+                if hit is not None:
+                    self._qcache.move_to_end(qkey)
+                    return hit.copy()
         if len(texts) <= batch_size or self._cached:      # (not `self.encode is not self._encode`: bound methods are never identical)
             if len(texts) <= batch_size:
                 params["prompts"] = texts
@@ -501,6 +517,11 @@ class HipBGEEmbeddingModel(BaseEmbeddingModel):
             results = results.float().cpu().numpy()
         if self.embedding_config.norm and not kwargs.get("normalize", True):
             results = (results.T / np.linalg.norm(results, axis=1)).T
+        if qkey is not None and isinstance(results, np.ndarray):
+            with self._qcache_lock:
+                self._qcache[qkey] = results.copy()
+                while len(self._qcache) > self._qcache_size:
+                    self._qcache.popitem(last=False)
         return results
 
     def batch_encode_dev(self, texts: Union[str, List[str]], **kwargs):

@@ -42,6 +42,7 @@ class BaseConfig:
     embedding_fused_encoder: bool = True          # 16-bit BERT encoders: HIP attention + bias/residual/LayerNorm stages, one QKV GEMM (embedding_model/fused_bert.py)
     embedding_devices: Optional[list] = None      # GPUs of the corpus-encode replicas (BGEEmbedding.py:77 `device_map="auto"`): one copy of the layer stack each, bucketing windows dealt round them; None = `device` only
     embedding_encode_replicas: int = 0            # > the device count: logical replicas going round `embedding_devices` (rehearsal on a one-GPU box); 0 = one per device
+    embedding_query_cache: int = 256              # single-string batch_encode results kept (by prompt, max_length, normalisation): a question is encoded three times per tri_retrieve — the same prompt each time; 0 = off
     embedding_gelu: str = "exact"                 # fused encoder: "exact" = erf-form GELU kernel (the reference's function); "epilogue" = opt-in: FFN-up bias + GELU inside the hipBLASLt GEMM (TANH form, <= 4.8e-4 per activation away, ~7 % faster forward)
 
 

@@ -316,7 +316,7 @@ def test_captured_graphs_equal_eager_forwards_also_from_many_threads():
     mk = lambda **kw: cls(global_config=BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=8, embedding_max_seq_len=128,
                                                    embedding_model_dtype="bf16", **kw),
                           embedding_model_name="bge-tiny-random", model=copy.deepcopy(model), tokenizer=tok)
-    em, eager = mk(), mk(embedding_hip_graphs=0)
+    em, eager = mk(embedding_query_cache=0), mk(embedding_hip_graphs=0, embedding_query_cache=0)      # (every call below is a forward, not a cached row)
     queries = ["midnight", "what did the mother wish " * 3, "the prince and the golden slipper " * 6, "she was good and pious " * 12,
                "who how when", "the bird in the tree and the king and his son went to the dance " * 2]
     want = [eager.batch_encode(q) for q in queries]
@@ -334,6 +334,43 @@ def test_captured_graphs_equal_eager_forwards_also_from_many_threads():
     for i, g in enumerate(got):
         np.testing.assert_allclose(g, want[i % len(queries)], atol=2e-6)
     em.close(); eager.close()
+
+
+def test_single_string_results_are_kept_and_handed_back_as_copies():
+    """ComoRAG encodes a question three times per tri_retrieve (ComoRAG.py:921-935 once per instruction — which its BGE model ignores — and
+    get_similar_summaries once more): HipBGEEmbeddingModel keeps the last `embedding_query_cache` single-string results by (prompt, max_length,
+    normalisation).  A hit is the first call's row, a COPY of it (the caller may scribble on it), keyed on what changes the row; bounded;
+    lists of strings and device-resident results never look there; 0 switches it off."""
+    import torch
+    from comorag_amd.embedding_model import _get_embedding_model_class
+    from comorag_amd.utils.config_utils import BaseConfig
+    model, tok = _peaked_tiny_bert(torch.bfloat16)
+    cls = _get_embedding_model_class("bge-tiny-random")
+    mk = lambda **kw: cls(global_config=BaseConfig(embedding_model_name="bge-tiny-random", embedding_batch_size=8, embedding_max_seq_len=128,
+                                                   embedding_model_dtype="bf16", **kw),
+                          embedding_model_name="bge-tiny-random", model=copy.deepcopy(model), tokenizer=tok)
+    em, off = mk(embedding_query_cache=3), mk(embedding_query_cache=0)
+    forwards = []
+    real = em._encode
+    em._encode = em.encode = lambda *a, **k: (forwards.append(1), real(*a, **k))[1]
+    a = em.batch_encode("who lost a slipper", instruction="query_to_fact", norm=True)
+    b = em.batch_encode("who lost a slipper", instruction="query_to_passage", norm=True)          # the instruction is overwritten by the fixed prefix: same prompt
+    assert len(forwards) == 1 and np.array_equal(a, b) and a is not b
+    np.testing.assert_array_equal(a, off.batch_encode("who lost a slipper"))
+    a[:] = 7.0                                                                                      # a caller's scribble stays the caller's
+    assert np.array_equal(em.batch_encode("who lost a slipper"), b) and len(forwards) == 1
+    em.batch_encode("who lost a slipper", max_length=8); em.batch_encode("who lost a slipper", normalize=False)
+    assert len(forwards) == 3                                                                       # other rows: other keys
+    em.batch_encode(["who lost a slipper"] * 2); em.batch_encode_dev("who lost a slipper")
+    assert len(forwards) == 5                                                                       # lists and device results are not cached
+    for q in ("one", "two", "three"):
+        em.batch_encode(q)
+    n = len(forwards)
+    em.batch_encode("who lost a slipper")                                                           # evicted by three newer keys
+    assert len(forwards) == n + 1 and len(em._qcache) == 3
+    off.batch_encode("midnight"); off.batch_encode("midnight")
+    assert len(off._qcache) == 0
+    em.close(); off.close()
 
 
 @pytest.mark.timeout(600)

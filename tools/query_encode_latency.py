@@ -20,7 +20,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     tok, words = synthetic_wordpiece_tokenizer()
     for kind, dtype in (("base", "bf16"), ("large", "fp16")):
-        cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_model_dtype=dtype)
+        cfg = BaseConfig(embedding_model_name=f"bge-{kind}-random-init", embedding_model_dtype=dtype, embedding_query_cache=0)      # (every call a forward: the product keeps the last 256 single-string rows)
         em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert(kind, vocab_size=len(tok)), tokenizer=tok)
         q = " ".join(words[:12])
         for _ in range(8):

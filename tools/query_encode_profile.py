@@ -6,7 +6,7 @@ from comorag_amd.embedding_model.bge import HipBGEEmbeddingModel
 from comorag_amd.utils.config_utils import BaseConfig
 from tools.synthetic import random_bert, synthetic_wordpiece_tokenizer
 tok, words = synthetic_wordpiece_tokenizer()
-cfg = BaseConfig(embedding_model_name="bge-base-random-init", embedding_model_dtype="bf16")
+cfg = BaseConfig(embedding_model_name="bge-base-random-init", embedding_model_dtype="bf16", embedding_query_cache=0)
 em = HipBGEEmbeddingModel(cfg, cfg.embedding_model_name, model=random_bert("base", vocab_size=len(tok)), tokenizer=tok)
 q = " ".join(words[:12])
 for _ in range(10): em.batch_encode(q)
